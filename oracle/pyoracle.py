@@ -1,0 +1,373 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/liboracle.so (the CPU restatement of the Java reference).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The product package
+(boofcv_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    """Compile liboracle.so with g++ (seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_capi.cpp", "boof_oracle.hpp", "boof_oracle_ip.hpp")]
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class _Image(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_float)), ("startIndex", C.c_int), ("stride", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+class FhCfg(C.Structure):
+    """F:abst/feature/detect/interest/ConfigFastHessian.java:33-70"""
+    _fields_ = [("detectThreshold", C.c_float), ("extractRadius", C.c_int), ("maxFeaturesPerScale", C.c_int), ("initialSampleSize", C.c_int),
+                ("initialSize", C.c_int), ("numberScalesPerOctave", C.c_int), ("numberOfOctaves", C.c_int), ("scaleStepSize", C.c_int)]
+
+    def __init__(self, detectThreshold=1.0, extractRadius=2, maxFeaturesPerScale=-1, initialSampleSize=1, initialSize=9,
+                 numberScalesPerOctave=4, numberOfOctaves=4, scaleStepSize=6):
+        super().__init__(detectThreshold, extractRadius, maxFeaturesPerScale, initialSampleSize, initialSize, numberScalesPerOctave,
+                         numberOfOctaves, scaleStepSize)
+
+
+class SurfCfg(C.Structure):
+    """F:abst/feature/describe/ConfigSurfDescribe.java:34-78"""
+    _fields_ = [("widthLargeGrid", C.c_int), ("widthSubRegion", C.c_int), ("widthSample", C.c_int), ("weightSigma", C.c_double),
+                ("overLap", C.c_int), ("sigmaLargeGrid", C.c_double), ("sigmaSubRegion", C.c_double)]
+
+    def __init__(self, widthLargeGrid=4, widthSubRegion=5, widthSample=3, weightSigma=4.5, overLap=2, sigmaLargeGrid=2.5, sigmaSubRegion=2.5):
+        super().__init__(widthLargeGrid, widthSubRegion, widthSample, weightSigma, overLap, sigmaLargeGrid, sigmaSubRegion)
+
+
+class OriCfg(C.Structure):
+    """ConfigSlidingIntegral.java:34-54 / ConfigAverageIntegral.java:34-51 (windowSize unused by the average variant)"""
+    _fields_ = [("objectRadiusToScale", C.c_double), ("samplePeriod", C.c_double), ("windowSize", C.c_double), ("radius", C.c_int),
+                ("weightSigma", C.c_double), ("sampleWidth", C.c_int)]
+
+    @staticmethod
+    def sliding(samplePeriod=0.65, windowSize=np.pi / 3.0, radius=8, weightSigma=-1.0, sampleWidth=6):
+        return OriCfg(0.5, samplePeriod, windowSize, radius, weightSigma, sampleWidth)
+
+    @staticmethod
+    def average(radius=6, samplePeriod=1.0, sampleWidth=6, weightSigma=-1.0):
+        return OriCfg(0.5, samplePeriod, 0.0, radius, weightSigma, sampleWidth)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        P = C.POINTER
+        IM = P(_Image)
+        sig = {
+            "orc_max_threads": (C.c_int, []),
+            "orc_rand_new": (C.c_void_p, [C.c_int64]),
+            "orc_rand_free": (None, [C.c_void_p]),
+            "orc_rand_next_int": (C.c_int32, [C.c_void_p]),
+            "orc_rand_next_int_bound": (C.c_int32, [C.c_void_p, C.c_int32]),
+            "orc_rand_next_float": (C.c_float, [C.c_void_p]),
+            "orc_rand_next_double": (C.c_double, [C.c_void_p]),
+            "orc_rand_next_gaussian": (C.c_double, [C.c_void_p]),
+            "orc_rand_next_boolean": (C.c_int, [C.c_void_p]),
+            "orc_fill_uniform": (None, [C.c_void_p, IM, C.c_float, C.c_float]),
+            "orc_fill_gaussian": (None, [C.c_void_p, IM, C.c_double, C.c_double, C.c_float, C.c_float]),
+            "orc_integral": (None, [IM, IM]),
+            "orc_block_unsafe": (C.c_float, [IM, C.c_int, C.c_int, C.c_int, C.c_int]),
+            "orc_block_zero": (C.c_float, [IM, C.c_int, C.c_int, C.c_int, C.c_int]),
+            "orc_convolve_sparse": (C.c_float, [IM, C.c_int, C.c_int, C.c_int, C.c_int]),
+            "orc_convolve_sparse_blocks": (C.c_float, [IM, C.c_int, P(C.c_int), P(C.c_int), C.c_int, C.c_int]),
+            "orc_hessian": (None, [IM, C.c_int, C.c_int, IM, C.c_int, C.c_int]),
+            "orc_nonmax": (C.c_int, [IM, C.c_int, C.c_float, C.c_int, C.c_int, P(C.c_int16), C.c_int, C.c_int]),
+            "orc_fh_detect": (C.c_int, [IM, P(FhCfg), P(C.c_double), C.c_int, C.c_int]),
+            "orc_orientation": (C.c_double, [IM, C.c_int, P(OriCfg), C.c_double, C.c_double, C.c_double]),
+            "orc_sparse_gradient": (C.c_int, [IM, C.c_double, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
+            "orc_describe": (None, [IM, C.c_int, P(SurfCfg), C.c_double, C.c_double, C.c_double, C.c_double, P(C.c_double), P(C.c_uint8), C.c_int]),
+            "orc_gaussian_width": (C.c_int, [C.c_double, C.c_int, P(C.c_double)]),
+            "orc_gaussian2d_f64": (C.c_int, [C.c_double, C.c_int, P(C.c_double)]),
+            "orc_gaussian1d_f32": (C.c_int, [C.c_double, C.c_int, P(C.c_float)]),
+            "orc_surf_create": (C.c_void_p, [C.c_int, P(FhCfg), P(SurfCfg), P(OriCfg)]),
+            "orc_surf_destroy": (None, [C.c_void_p]),
+            "orc_surf_detect": (C.c_int, [C.c_void_p, IM, C.c_int]),
+            "orc_surf_describe_points": (C.c_int, [C.c_void_p, IM, P(C.c_double), C.c_int, C.c_int]),
+            "orc_surf_fetch": (None, [C.c_void_p, P(C.c_double), P(C.c_double), P(C.c_uint8), P(C.c_double)]),
+            "orc_surf_integral": (None, [C.c_void_p, P(C.c_float)]),
+            "orc_associate_l2": (None, [P(C.c_double), C.c_int, P(C.c_double), C.c_int, C.c_int, C.c_double, C.c_int, P(C.c_int), P(C.c_double), C.c_int]),
+            "orc_associate_euclidean": (None, [P(C.c_double), C.c_int, P(C.c_double), C.c_int, C.c_int, C.c_double, C.c_int, P(C.c_int), P(C.c_double), C.c_int]),
+            "orc_associate_hamming": (None, [P(C.c_int32), C.c_int, P(C.c_int32), C.c_int, C.c_int, C.c_double, C.c_int, P(C.c_int), P(C.c_double), C.c_int]),
+            "orc_euclidean_sq": (C.c_double, [P(C.c_double), P(C.c_double), C.c_int]),
+            "orc_hamming_word": (C.c_int, [C.c_int32]),
+            "orc_hamming": (C.c_int, [P(C.c_int32), P(C.c_int32), C.c_int]),
+            "orc_brief_definition": (None, [C.c_int64, C.c_int, C.c_int, P(C.c_int), P(C.c_int)]),
+            "orc_brief_describe": (None, [IM, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_double), C.c_int, P(C.c_int32)]),
+            "orc_conv_h": (None, [P(C.c_float), C.c_int, C.c_int, IM, IM, C.c_int]),
+            "orc_conv_v": (None, [P(C.c_float), C.c_int, C.c_int, IM, IM, C.c_int]),
+            "orc_conv_norm_h": (None, [P(C.c_float), C.c_int, C.c_int, IM, IM, C.c_int]),
+            "orc_conv_norm_v": (None, [P(C.c_float), C.c_int, C.c_int, IM, IM, C.c_int]),
+            "orc_gaussian_blur": (None, [IM, IM, C.c_double, C.c_int, IM, C.c_int]),
+            "orc_sobel": (None, [IM, IM, IM, C.c_int, C.c_int]),
+            "orc_three": (None, [IM, IM, IM, C.c_int, C.c_int]),
+            "orc_subsample": (None, [IM, IM, C.c_int]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+MAX_VALUE_F32 = np.float32(3.4028234663852886e38)  # Float.MAX_VALUE
+MAX_VALUE_F64 = 1.7976931348623157e308  # Double.MAX_VALUE
+
+
+def _fp(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Gray:
+    """GrayF32 view over a float32 numpy buffer: pixel(x,y) = buf[startIndex + y*stride + x]  (T:struct/image/ImageBase.java:34-52)."""
+
+    def __init__(self, width, height, buf=None, startIndex=0, stride=None):
+        self.width, self.height = int(width), int(height)
+        self.stride = int(stride if stride is not None else width)
+        self.startIndex = int(startIndex)
+        if buf is None:
+            buf = np.zeros(self.startIndex + self.stride * self.height, dtype=np.float32)
+        assert buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"]
+        self.buf = buf
+
+    @staticmethod
+    def from_array(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return Gray(a.shape[1], a.shape[0], a.reshape(-1))
+
+    def array(self):
+        """(height,width) strided view of the pixels."""
+        return np.lib.stride_tricks.as_strided(self.buf[self.startIndex:], shape=(self.height, self.width), strides=(4 * self.stride, 4))
+
+    def c(self):
+        return C.byref(_Image(_fp(self.buf), self.startIndex, self.stride, self.width, self.height))
+
+    def sub_image_of(self, pad_x=5, pad_y=7, fill=0.0):
+        """BoofTesting.createSubImageOf (I:testing/BoofTesting.java:71): same pixels inside a larger buffer."""
+        W, H = self.width + 2 * pad_x, self.height + 2 * pad_y
+        big = np.full(W * H, fill, dtype=np.float32)
+        g = Gray(self.width, self.height, big, startIndex=pad_y * W + pad_x, stride=W)
+        g.array()[:, :] = self.array()
+        return g
+
+
+class JavaRandom:
+    """java.util.Random (48-bit LCG)."""
+
+    def __init__(self, seed):
+        self._h = lib().orc_rand_new(int(seed))
+
+    def __del__(self):
+        try:
+            lib().orc_rand_free(self._h)
+        except Exception:
+            pass
+
+    def nextInt(self, bound=None):
+        return lib().orc_rand_next_int(self._h) if bound is None else lib().orc_rand_next_int_bound(self._h, bound)
+
+    def nextFloat(self):
+        return lib().orc_rand_next_float(self._h)
+
+    def nextDouble(self):
+        return lib().orc_rand_next_double(self._h)
+
+    def nextGaussian(self):
+        return lib().orc_rand_next_gaussian(self._h)
+
+    def nextBoolean(self):
+        return bool(lib().orc_rand_next_boolean(self._h))
+
+    def fillUniform(self, img, lo, hi):
+        lib().orc_fill_uniform(self._h, img.c(), lo, hi)
+        return img
+
+    def fillGaussian(self, img, mean, sigma, lo, hi):
+        lib().orc_fill_gaussian(self._h, img.c(), mean, sigma, lo, hi)
+        return img
+
+
+def noise_image(width, height, seed, lo=0.0, hi=100.0):
+    """S-noise(W,H,seed) of SURVEY 8d: ImageMiscOps.fillUniform with java.util.Random(seed)."""
+    return JavaRandom(seed).fillUniform(Gray(width, height), lo, hi)
+
+
+def integral(img):
+    out = Gray(img.width, img.height)
+    lib().orc_integral(img.c(), out.c())
+    return out
+
+
+def hessian(ii, skip, size, naive=False, threads=1):
+    out = Gray(ii.width // skip, ii.height // skip)
+    lib().orc_hessian(ii.c(), skip, size, out.c(), 1 if naive else 0, threads)
+    return out
+
+
+def nonmax(intensity, radius, threshold, border, naive=False, threads=1):
+    cap = intensity.width * intensity.height
+    out = np.zeros((cap, 2), dtype=np.int16)
+    n = lib().orc_nonmax(intensity.c(), radius, threshold, border, 1 if naive else 0, _fp(out, C.c_int16), cap, threads)
+    return out[:n].copy()
+
+
+def fh_detect(ii, cfg=None, threads=1):
+    cfg = cfg or FhCfg()
+    cap = 1 << 16
+    while True:
+        out = np.zeros((cap, 3), dtype=np.float64)
+        n = lib().orc_fh_detect(ii.c(), C.byref(cfg), _fp(out, C.c_double), cap, threads)
+        if n <= cap:
+            return out[:n].copy()
+        cap = n
+
+
+def orientation(ii, x, y, objectRadius, kind="sliding", cfg=None):
+    k = 0 if kind == "sliding" else 1
+    cfg = cfg or (OriCfg.sliding() if k == 0 else OriCfg.average())
+    return lib().orc_orientation(ii.c(), k, C.byref(cfg), x, y, objectRadius)
+
+
+def describe(ii, x, y, angle, scale, stable=True, cfg=None, normalize=True):
+    cfg = cfg or SurfCfg()
+    desc = np.zeros(cfg.widthLargeGrid * cfg.widthLargeGrid * 4, dtype=np.float64)
+    white = C.c_uint8(0)
+    lib().orc_describe(ii.c(), 1 if stable else 0, C.byref(cfg), x, y, angle, scale, _fp(desc, C.c_double), C.byref(white), 1 if normalize else 0)
+    return desc, bool(white.value)
+
+
+class Surf:
+    """FactoryDetectDescribe.surfStable / surfFast (F:factory/feature/detdesc/FactoryDetectDescribe.java:118-135,209-226)."""
+
+    def __init__(self, stable=True, fh=None, sd=None, ori=None):
+        self.stable = stable
+        self.fh = fh or FhCfg()
+        self.sd = sd or SurfCfg()
+        self.ori = ori or (OriCfg.sliding() if stable else OriCfg.average())
+        self.dof = self.sd.widthLargeGrid * self.sd.widthLargeGrid * 4
+        self._h = lib().orc_surf_create(1 if stable else 0, C.byref(self.fh), C.byref(self.sd), C.byref(self.ori))
+        self.n = 0
+
+    def __del__(self):
+        try:
+            lib().orc_surf_destroy(self._h)
+        except Exception:
+            pass
+
+    def detect(self, img, threads=1):
+        self.n = lib().orc_surf_detect(self._h, img.c(), threads)
+        self._shape = (img.width, img.height)
+        return self.n
+
+    def describe_points(self, xys, img=None, threads=1):
+        xys = np.ascontiguousarray(xys, dtype=np.float64)
+        self.n = lib().orc_surf_describe_points(self._h, img.c() if img is not None else None, _fp(xys, C.c_double), len(xys), threads)
+        return self.n
+
+    def fetch(self):
+        n = self.n
+        xys = np.zeros((n, 3)); ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); desc = np.zeros((n, self.dof))
+        lib().orc_surf_fetch(self._h, _fp(xys, C.c_double), _fp(ang, C.c_double), _fp(white, C.c_uint8), _fp(desc, C.c_double))
+        return xys, ang, white, desc
+
+    def integral(self):
+        w, h = self._shape
+        out = np.zeros((h, w), dtype=np.float32)
+        lib().orc_surf_integral(self._h, _fp(out))
+        return out
+
+
+def associate_l2(src, dst, maxErr=MAX_VALUE_F64, backwards=True, threads=1, sqrt_score=False):
+    """AssociateGreedy + ScoreAssociateEuclideanSq_F64 (or ScoreAssociateEuclidean_F64 when sqrt_score)
+    -> (pairs int32[ns], fitQuality float64[ns])."""
+    src = np.ascontiguousarray(src, dtype=np.float64); dst = np.ascontiguousarray(dst, dtype=np.float64)
+    ns, nd = len(src), len(dst)
+    dof = src.shape[1] if ns else (dst.shape[1] if nd else 0)
+    pairs = np.zeros(ns, dtype=np.int32); fit = np.zeros(ns, dtype=np.float64)
+    fn = lib().orc_associate_euclidean if sqrt_score else lib().orc_associate_l2
+    fn(_fp(src, C.c_double), ns, _fp(dst, C.c_double), nd, dof, maxErr, int(backwards), _fp(pairs, C.c_int), _fp(fit, C.c_double), threads)
+    return pairs, fit
+
+
+def associate_hamming(src, dst, maxErr=MAX_VALUE_F64, backwards=True, threads=1):
+    """AssociateGreedy + ScoreAssociateHamming_B on int32 words."""
+    src = np.ascontiguousarray(src, dtype=np.int32); dst = np.ascontiguousarray(dst, dtype=np.int32)
+    ns, nd = len(src), len(dst)
+    words = src.shape[1] if ns else (dst.shape[1] if nd else 0)
+    pairs = np.zeros(ns, dtype=np.int32); fit = np.zeros(ns, dtype=np.float64)
+    lib().orc_associate_hamming(_fp(src, C.c_int32), ns, _fp(dst, C.c_int32), nd, words, maxErr, int(backwards), _fp(pairs, C.c_int), _fp(fit, C.c_double), threads)
+    return pairs, fit
+
+
+def brief_definition(seed=123, radius=16, numPoints=512):
+    sp = np.zeros((numPoints, 2), dtype=np.int32); cmp_ = np.zeros((numPoints, 2), dtype=np.int32)
+    lib().orc_brief_definition(seed, radius, numPoints, _fp(sp, C.c_int), _fp(cmp_, C.c_int))
+    return sp, cmp_
+
+
+def brief_describe(img, xy, radius, samplePoints, compare):
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    n = len(xy); npts = len(samplePoints)
+    out = np.zeros((n, (npts + 31) // 32), dtype=np.int32)
+    sp = np.ascontiguousarray(samplePoints, dtype=np.int32); cp = np.ascontiguousarray(compare, dtype=np.int32)
+    lib().orc_brief_describe(img.c(), radius, npts, _fp(sp, C.c_int), _fp(cp, C.c_int), _fp(xy, C.c_double), n, _fp(out, C.c_int32))
+    return out
+
+
+def _kernel(k):
+    k = np.ascontiguousarray(k, dtype=np.float32)
+    return k, _fp(k)
+
+
+def conv(kind, kernel, offset, src, threads=1):
+    """kind in {'h','v','norm_h','norm_v'}; returns a new Gray (border of the no-border variants left at 0)."""
+    k, kp = _kernel(kernel)
+    out = Gray(src.width, src.height)
+    getattr(lib(), "orc_conv_" + kind)(kp, len(k), offset, src.c(), out.c(), threads)
+    return out
+
+
+def gaussian_blur(src, sigma, radius, threads=1):
+    out = Gray(src.width, src.height); storage = Gray(src.width, src.height)
+    lib().orc_gaussian_blur(src.c(), out.c(), sigma, radius, storage.c(), threads)
+    return out
+
+
+def gradient(kind, src, border_zero=False, threads=1):
+    dx = Gray(src.width, src.height); dy = Gray(src.width, src.height)
+    getattr(lib(), "orc_" + kind)(src.c(), dx.c(), dy.c(), int(border_zero), threads)
+    return dx, dy
+
+
+def gaussian1d_f32(sigma, radius):
+    out = np.zeros(4096, dtype=np.float32)
+    w = lib().orc_gaussian1d_f32(sigma, radius, _fp(out))
+    return out[:w].copy()
+
+
+def gaussian_width(sigma, width):
+    out = np.zeros(width * width + 64, dtype=np.float64)
+    w = lib().orc_gaussian_width(sigma, width, _fp(out, C.c_double))
+    return out[:w * w].reshape(w, w).copy()
+
+
+def gaussian2d_f64(sigma, radius):
+    out = np.zeros(65 * 65, dtype=np.float64)
+    w = lib().orc_gaussian2d_f64(sigma, radius, _fp(out, C.c_double))
+    return out[:w * w].reshape(w, w).copy()

@@ -1,0 +1,447 @@
+"""Pins the CPU oracle (oracle/) against the reference's own known-answer / property tests.
+
+Each test names the Java test it re-expresses.  FT: = main/boofcv-feature/src/test/java/boofcv/,
+IT: = main/boofcv-ip/src/test/java/boofcv/ under the reference tree.  No GPU, no product code here.
+"""
+import math
+
+import numpy as np
+import pytest
+
+
+# ---------------------------------------------------------------------------------------------------
+# java.util.Random: values fixed by the Java SE specification (widely published first outputs)
+# ---------------------------------------------------------------------------------------------------
+def test_java_random_known_values(orc):
+    assert orc.JavaRandom(0).nextInt() == -1155484576
+    assert orc.JavaRandom(42).nextInt() == -1170105035
+    assert orc.JavaRandom(0).nextDouble() == 0.730967787376657
+    assert orc.JavaRandom(0).nextFloat() == np.float32(0.73096776)
+    assert abs(orc.JavaRandom(0).nextGaussian() - 0.8025330637390305) < 1e-15
+    r = orc.JavaRandom(0)
+    assert [r.nextInt(10) for _ in range(5)] == [0, 8, 9, 7, 5]
+    # power-of-two bound: (bound * next(31)) >> 31 == the top log2(bound) bits of next(32)
+    r = orc.JavaRandom(0); q = orc.JavaRandom(0)
+    assert [r.nextInt(16) for _ in range(8)] == [(q.nextInt() & 0xFFFFFFFF) >> 28 for _ in range(8)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# IT:alg/transform/ii/impl/TestImplIntegralImageOps.java
+# ---------------------------------------------------------------------------------------------------
+W, H = 20, 30
+
+
+def test_integral_transform_and_subimage(orc):  # :69-89
+    rand = orc.JavaRandom(234)
+    img = rand.fillUniform(orc.Gray(W, H), 0, 100)
+    for sub in (False, True):
+        a = img.sub_image_of() if sub else img
+        b = orc.Gray(W, H).sub_image_of(3, 2) if sub else orc.Gray(W, H)
+        orc.lib().orc_integral(a.c(), b.c())
+        expected = np.cumsum(np.cumsum(img.array().astype(np.float64), axis=0), axis=1)
+        assert np.max(np.abs(expected - b.array())) < 1e-1
+
+
+def test_block_sums_on_ones(orc):  # :131-145, :153-180
+    ii = orc.integral(orc.Gray.from_array(np.ones((H, W), np.float32)))
+    L = orc.lib()
+    assert L.orc_block_unsafe(ii.c(), 4, 5, 8, 8) == 12
+    assert L.orc_block_zero(ii.c(), 4, 5, 8, 8) == 12
+    assert L.orc_block_zero(ii.c(), -1, -2, 2, 3) == 12
+    assert L.orc_block_zero(ii.c(), W - 2, H - 3, W + 1, H + 3) == 2
+    assert L.orc_block_zero(ii.c(), 3, -4, -1, -1) == 0
+    assert L.orc_block_zero(ii.c(), W + 1, H + 2, W + 6, H + 8) == 0
+
+
+def test_convolve_sparse_equals_dense(orc):  # :97-123
+    import ctypes as C
+    rand = orc.JavaRandom(234)
+    ii = rand.fillUniform(orc.Gray(W, H), 0, 1000)
+    blocks = np.array([-2, -2, 1, 1, -2, -1, 1, 0], dtype=np.int32)
+    scales = np.array([1, 2], dtype=np.int32)
+    A = ii.array().astype(np.float64)
+
+    def bz(x0, y0, x1, y1):  # dense restatement of block_zero in float64
+        x0, y0, x1, y1 = min(x0, W - 1), min(y0, H - 1), min(x1, W - 1), min(y1, H - 1)
+        g = lambda x, y: A[y, x] if x >= 0 and y >= 0 else 0.0
+        return g(x1, y1) - g(x1, y0) - g(x0, y1) + g(x0, y0)
+
+    for (x, y) in [(0, 0), (10, 12), (19, 29)]:
+        found = orc.lib().orc_convolve_sparse_blocks(ii.c(), 2, blocks.ctypes.data_as(C.POINTER(C.c_int)), scales.ctypes.data_as(C.POINTER(C.c_int)), x, y)
+        exp = sum(bz(x + blocks[4 * i], y + blocks[4 * i + 1], x + blocks[4 * i + 2], y + blocks[4 * i + 3]) * scales[i] for i in range(2))
+        assert abs(found - exp) < 1e-2 * max(1, abs(exp)) * 1e-2 + 1e-1  # fp32 sums of O(1e3) values
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/detect/intensity/TestIntegralImageFeatureIntensity.java:45-65 (+ impl test :44-69)
+# ---------------------------------------------------------------------------------------------------
+def test_hessian_inner_border_equals_naive(orc):
+    rand = orc.JavaRandom(234)
+    ii = orc.integral(rand.fillUniform(orc.Gray(60, 70), 0, 50))
+    for skip in range(1, 5):
+        expected = orc.hessian(ii, skip, 9, naive=True)
+        found = orc.hessian(ii, skip, 9)
+        assert expected.array().shape == (70 // skip, 60 // skip)
+        assert np.max(np.abs(expected.array() - found.array())) <= 1e-4
+    # the octave schedule's other sizes and a multi-threaded run agree too
+    for skip, size in [(1, 15), (2, 27), (2, 51), (4, 27)]:
+        e = orc.hessian(ii, skip, size, naive=True).array()
+        f = orc.hessian(ii, skip, size, threads=4).array()
+        assert np.max(np.abs(e - f)) <= 1e-4 * max(1.0, np.max(np.abs(e)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/detect/extract/GenericNonMaxTests.java (strict, max only) + GeneralNonMaxSuppressionChecks.java:231
+# ---------------------------------------------------------------------------------------------------
+NW, NH = 30, 40
+
+
+def _blank():
+    return np.zeros((NH, NW), np.float32)
+
+
+def test_nonmax_border_maximum(orc):  # :94-124
+    a = _blank(); a[1, 0] = 90; a[1, 1] = 30
+    assert len(orc.nonmax(orc.Gray.from_array(a), 1, 5, 0)) == 1
+    assert len(orc.nonmax(orc.Gray.from_array(a), 1, 5, 1)) == 0
+
+
+def test_nonmax_along_image_border(orc):  # :126-150
+    a = _blank()
+    a[0, NW // 2] = 90; a[NH - 1, NW // 2] = 90; a[NH // 2, 0] = 90; a[NH // 2, NW - 1] = 90
+    assert len(orc.nonmax(orc.Gray.from_array(a), 2, 5, 0)) == 4
+
+
+def test_nonmax_strict_rule(orc):  # :159-175
+    a = _blank()
+    a[5, 3] = 30; a[7, 5] = 30; a[7, 7] = 30
+    a[5, 2] = -30; a[7, 4] = -30; a[7, 6] = -30
+    assert len(orc.nonmax(orc.Gray.from_array(a), 2, 5, 0)) == 0
+
+
+def test_nonmax_ignores_max_value(orc):  # GeneralNonMaxSuppressionChecks.java:231
+    a = _blank(); a[10, 10] = orc.MAX_VALUE_F32; a[20, 20] = 50
+    found = orc.nonmax(orc.Gray.from_array(a), 2, 5, 0)
+    assert found.tolist() == [[20, 20]]
+
+
+def test_nonmax_block_equals_naive_as_sets(orc):  # :200-262
+    rand = orc.JavaRandom(2134)
+    for use_sub in (False, True):
+        for radius in (1, 2, 3, 4):
+            for _ in range(10):
+                img = rand.fillGaussian(orc.Gray(NW, NH), 0, 3, -100, 100)
+                if use_sub:
+                    img = img.sub_image_of(5, 4)
+                found = orc.nonmax(img, radius, 0.6, 0)
+                naive = orc.nonmax(img, radius, 0.6, 0, naive=True)
+                assert len(found) > 0 and len(found) == len(naive)
+                assert set(map(tuple, found)) == set(map(tuple, naive))
+                # block-raster order: keys strictly increasing
+                step = radius + 1
+                keys = [(y // step) * 1000 + (x // step) for x, y in found]
+                assert keys == sorted(keys) and len(set(keys)) == len(keys)
+                # threaded variant merges in the same order
+                assert np.array_equal(orc.nonmax(img, radius, 0.6, 0, threads=3), found)
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/detect/interest/GenericFeatureDetectorTests.java:52-123 with TestFastHessianFeatureDetector.java:37-40
+# ---------------------------------------------------------------------------------------------------
+def _checkered(orc, w=80, h=90, sq=10, seed=234):
+    """GenericFeatureDetectorTests.renderCheckered (:151-167): 50/0 squares + U[-5,5) noise."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.where(((xx // sq) + (yy // sq)) % 2 == 0, 50.0, 0.0).astype(np.float32)
+    noise = orc.JavaRandom(seed).fillUniform(orc.Gray(w, h), -5, 5).array()
+    return orc.Gray.from_array(a + noise)
+
+
+def test_fast_hessian_detector_generic(orc):
+    # FH(extractor(r=1,thr=1,border 5), maxPerScale, 1, 9, 4, 4, 6)
+    img = _checkered(orc)
+    ii = orc.integral(img)
+    n_all = len(orc.fh_detect(ii, orc.FhCfg(1.0, 1, -1, 1, 9, 4, 4, 6)))
+    n_20 = len(orc.fh_detect(ii, orc.FhCfg(1.0, 1, 20, 1, 9, 4, 4, 6)))
+    n_10 = len(orc.fh_detect(ii, orc.FhCfg(1.0, 1, 10, 1, 9, 4, 4, 6)))
+    assert n_all > 0 and n_10 <= n_20 <= n_all and n_10 < n_all  # checkFlags / maxFeatures monotone
+    # idempotent (checkMultipleCalls)
+    assert np.array_equal(orc.fh_detect(ii, orc.FhCfg(1.0, 1, -1, 1, 9, 4, 4, 6)), orc.fh_detect(ii, orc.FhCfg(1.0, 1, -1, 1, 9, 4, 4, 6)))
+    # blank image has fewer features than the checkered one
+    blank = orc.integral(orc.Gray.from_array(np.full((90, 80), 50, np.float32)))
+    assert len(orc.fh_detect(blank, orc.FhCfg(1.0, 1, -1, 1, 9, 4, 4, 6))) < n_all
+
+
+def test_fast_hessian_threads_do_not_change_order(orc):
+    ii = orc.integral(orc.noise_image(200, 150, 77))
+    a = orc.fh_detect(ii, threads=1)
+    b = orc.fh_detect(ii, threads=4)
+    assert len(a) > 50 and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/orientation/GenericOrientationIntegralTests.java:98-170,200-216
+# ---------------------------------------------------------------------------------------------------
+def _oriented(orc, angle, w=30, h=40):
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = (10 * (xx * math.cos(angle) + yy * math.sin(angle))).astype(np.float32)
+    return orc.integral(orc.Gray.from_array(a))
+
+
+def _adist(a, b):
+    d = abs(a - b) % (2 * math.pi)
+    return min(d, 2 * math.pi - d)
+
+
+@pytest.mark.parametrize("kind,tol,cfg", [
+    ("sliding", math.pi / 9, lambda o: o.OriCfg(0.3, 1.0, math.pi / 3, 3, 0.0, 4)),   # TestImplOrientationSlidingWindowIntegral r=3
+    ("sliding", math.pi / 9, lambda o: o.OriCfg(0.3, 1.0, math.pi / 3, 3, -1.0, 4)),
+    ("average", 0.01, lambda o: o.OriCfg(0.5, 1.0, 0.0, 4, 0.0, 2)),                   # TestImplOrientationAverageGradientIntegral r=4
+    ("average", 0.01, lambda o: o.OriCfg(0.5, 1.0, 0.0, 4, -1.0, 2)),
+])
+def test_orientation_planar_ramp(orc, kind, tol, cfg):
+    c = cfg(orc)
+    N = 2 * int(math.pi / tol)
+    for i in range(N):
+        angle = i * tol
+        ii = _oriented(orc, angle)
+        found = orc.orientation(ii, 15, 20, 10, kind, c)
+        assert _adist(angle, found) < tol
+    angle = (N // 2) * tol
+    ii = _oriented(orc, angle)
+    for radius in (10, 15, 7.5):  # setScale
+        assert _adist(angle, orc.orientation(ii, 15, 20, radius, kind, c)) < tol
+    # checkBorderExplode: no crash along the border
+    for y in range(40):
+        orc.orientation(ii, 0, y, 10, kind, c); orc.orientation(ii, 29, y, 10, kind, c)
+
+
+def test_orientation_defaults_planar_ramp(orc):
+    for angle in (0.0, 0.5, 2.0, -1.2, 3.0):
+        ii = _oriented(orc, angle, 120, 100)
+        assert _adist(angle, orc.orientation(ii, 60, 50, 2 * 2.0, "sliding")) < math.pi / 9
+        assert _adist(angle, orc.orientation(ii, 60, 50, 2 * 2.0, "average")) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/describe/BaseTestDescribeSurf.java:139-212 (both DescribePointSurf and DescribePointSurfMod)
+# ---------------------------------------------------------------------------------------------------
+def _xramp(orc, w=50, h=60):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return orc.integral(orc.Gray.from_array((1.0 * xx + 0.0 * yy).astype(np.float32)))
+
+
+@pytest.mark.parametrize("stable", [True, False])
+def test_surf_descriptor_analytic(orc, stable):
+    ii = orc.integral(orc.Gray.from_array(np.full((60, 50), 50, np.float32)))
+    f, _ = orc.describe(ii, 20, 20, 0.75, 1, stable)
+    assert np.all(np.abs(f) < 1e-4)  # features_constant
+
+    ii = _xramp(orc)
+    f, _ = orc.describe(ii, 15, 15, 0.0, 1, stable)  # features_increasing, along x
+    for i in range(0, 64, 4):
+        assert abs(f[i] - f[i + 1]) < 1e-4 and f[i] > 0 and abs(f[i + 2]) < 1e-4 and abs(f[i + 3]) < 1e-4
+    f, _ = orc.describe(ii, 15, 15, math.pi / 2, 1, stable)  # along y
+    for i in range(0, 64, 4):
+        assert abs(-f[i + 2] - f[i + 3]) < 1e-4 and f[i + 2] < 0 and abs(f[i]) < 1e-4 and abs(f[i + 1]) < 1e-4
+    f, _ = orc.describe(ii, 25, 25, 0.0, 1.5, stable)  # features_fraction
+    for i in range(0, 64, 4):
+        assert abs(f[i] - f[i + 1]) < 1e-4 and f[i] > 0 and abs(f[i + 2]) < 1e-4 and abs(f[i + 3]) < 1e-4
+    assert abs(np.linalg.norm(f) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("stable", [True, False])
+def test_surf_descriptor_subimage_scale_rotation_border(orc, stable):
+    rand = orc.JavaRandom(234)
+    ii = rand.fillUniform(orc.Gray(50, 60), 0, 100)  # the reference fills the integral image directly
+    a, wa = orc.describe(ii, 25, 30, 0, 1, stable)
+    b, wb = orc.describe(ii.sub_image_of(), 25, 30, 0, 1, stable)
+    assert wa == wb and np.array_equal(a, b)  # checkSubImage
+    c, _ = orc.describe(ii, 25, 30, 0, 1.5, stable)
+    d, _ = orc.describe(ii, 25, 30, 1, 1, stable)
+    assert np.max(np.abs(a - c)) > 1e-4 and np.max(np.abs(a - d)) > 1e-4  # changeScale / changeRotation
+    for i in range(10):  # checkBorder: must not blow up
+        ang = 2 * math.pi * i / 10
+        f0, _ = orc.describe(ii, 0, 0, ang, 1, stable)
+        f1, _ = orc.describe(ii, 49, 59, ang, 1, stable)
+        assert np.all(np.isfinite(f0)) and np.all(np.isfinite(f1))
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:abst/feature/detdesc/GenericTestsDetectDescribePoint.java:83-205 ; TestWrapDetectDescribeSurf_MT.java:54-103
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stable", [True, False])
+def test_detect_describe_generic(orc, stable):
+    rand = orc.JavaRandom(234)
+    s = orc.Surf(stable)
+    for _ in range(10):
+        img = rand.fillUniform(orc.Gray(100, 120), 0, 100)
+        n = s.detect(img)
+        assert n > 5
+        xys, ang, white, desc = s.fetch()
+        assert not np.any(np.isnan(desc)) and not np.any(np.isnan(ang))
+        assert np.allclose(np.linalg.norm(desc, axis=1), 1, atol=1e-12)
+    # sub-image == full, repeat call == first call
+    n2 = s.detect(img.sub_image_of())
+    r2 = s.fetch()
+    assert n2 == n and all(np.array_equal(p, q) for p, q in zip((xys, ang, white, desc), r2))
+    s.detect(img)
+    assert all(np.array_equal(p, q) for p, q in zip((xys, ang, white, desc), s.fetch()))
+
+
+def test_detect_describe_mt_equals_st(orc):
+    img = orc.JavaRandom(234).fillUniform(orc.Gray(400, 300), 0, 100)
+    s = orc.Surf(True)
+    n1 = s.detect(img, threads=1); r1 = s.fetch()
+    n4 = s.detect(img, threads=4); r4 = s.fetch()
+    assert n1 == n4 and n1 > 200
+    assert all(np.array_equal(p, q) for p, q in zip(r1, r4))  # deterministic merge order in the oracle
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/descriptor/TestDescriptorDistance.java:47-56,166-188
+# ---------------------------------------------------------------------------------------------------
+def test_descriptor_distance(orc):
+    import ctypes as C
+    a = np.array([1, 2, 3, 4, 5], np.float64); b = np.array([2, -1, 7, -8, 10], np.float64)
+    P = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    assert orc.lib().orc_euclidean_sq(P(a), P(b), 5) == 195
+    hw = orc.lib().orc_hamming_word
+    assert [hw(0), hw(0x0800), hw(0x0001), hw(0x0101), hw(0x000F)] == [0, 1, 1, 2, 4]
+    assert hw(np.int32(np.uint32(0xF000000F)).item()) == 8
+    rand = orc.JavaRandom(234)
+    for _ in range(20):
+        x = np.array([rand.nextInt() for _ in range(16)], np.int32); y = np.array([rand.nextInt() for _ in range(16)], np.int32)
+        exp = sum(bin((int(p) ^ int(q)) & 0xFFFFFFFF).count("1") for p, q in zip(x, y))
+        I = lambda v: v.ctypes.data_as(C.POINTER(C.c_int32))
+        assert orc.lib().orc_hamming(I(x), I(y), 16) == exp
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/associate/TestAssociateGreedy.java:38-105 (score = ScoreAssociateEuclidean_F64)
+# ---------------------------------------------------------------------------------------------------
+def _col(*v):
+    return np.array(v, np.float64).reshape(-1, 1)
+
+
+def test_greedy_basic(orc):
+    pairs, fit = orc.associate_l2(_col(1, 2, 3, 4), _col(3, 4, 1, 40), 0.5, False, sqrt_score=True)
+    assert pairs.tolist() == [2, -1, 0, 1]
+    assert fit[0] == 0 and fit[2] == 0 and fit[3] == 0
+
+
+def test_greedy_max_error(orc):
+    assert orc.associate_l2(_col(1, 2, 3, 4), _col(3, 4, 1.1, 40), 10, False, sqrt_score=True)[0][1] == 2
+    assert orc.associate_l2(_col(1, 2, 3, 4), _col(3, 4, 1.1, 40), 0.1, False, sqrt_score=True)[0][1] == -1
+
+
+def test_greedy_backwards(orc):
+    pairs, fit = orc.associate_l2(_col(1, 2, 3, 8), _col(3, 4, 1, 10), 10, True, sqrt_score=True)
+    assert pairs.tolist() == [2, -1, 0, 3]
+    assert fit[0] == 0 and fit[2] == 0 and fit[3] == 2
+    assert fit[1] == orc.MAX_VALUE_F64  # rejected by backwards validation
+    # squared score variant used on the product path
+    pairs, fit = orc.associate_l2(_col(1, 2, 3, 8), _col(3, 4, 1, 10), 10, True)
+    assert pairs.tolist() == [2, -1, 0, 3] and fit[3] == 4
+
+
+def test_greedy_threads_equal(orc):
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(200, 8)); b = rng.normal(size=(180, 8))
+    p1, f1 = orc.associate_l2(a, b, threads=1); p4, f4 = orc.associate_l2(a, b, threads=4)
+    assert np.array_equal(p1, p4) and np.array_equal(f1, f4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# FT:alg/feature/describe/BaseTestDescribePointBinaryCompare.java:141-191
+# ---------------------------------------------------------------------------------------------------
+def test_brief_bit_order_and_border(orc):
+    rand = orc.JavaRandom(234)
+    img = rand.fillUniform(orc.Gray(40, 50), 0, 100)
+    sp, cp = orc.brief_definition(123, 5, 20)  # 20 pairs -> one word
+    assert np.all(np.hypot(sp[:, 0], sp[:, 1]) < 5) and np.all(cp[:, 0] == np.arange(20)) and np.all((cp[:, 1] >= 0) & (cp[:, 1] < 20))
+    A = img.array()
+    cx, cy = 20, 25
+    d = orc.brief_describe(img, [[cx, cy]], 5, sp, cp)[0]
+    n = len(cp)
+    for i in range(n):
+        a = A[cy + sp[cp[i, 0], 1], cx + sp[cp[i, 0], 0]]; b = A[cy + sp[cp[i, 1], 1], cx + sp[cp[i, 1], 0]]
+        bit = (int(d[0]) >> (n - i - 1)) & 1  # bit `compare.length-i-1` <=> pair i
+        assert bit == (1 if a < b else 0)
+    # 512-bit default definition: pair i of a 32-group at bit 31-(i mod 32)
+    sp, cp = orc.brief_definition()
+    img = rand.fillUniform(orc.Gray(80, 70), 0, 100); A = img.array()
+    d = orc.brief_describe(img, [[40.7, 35.2]], 16, sp, cp)[0]
+    for i in range(512):
+        a = A[35 + sp[cp[i, 0], 1], 40 + sp[cp[i, 0], 0]]; b = A[35 + sp[cp[i, 1], 1], 40 + sp[cp[i, 1], 0]]
+        assert ((int(d[i // 32]) >> (31 - i % 32)) & 1) == (1 if a < b else 0)
+    # border path: pairs with a sample outside are skipped without shifting; never reads outside
+    d = orc.brief_describe(img, [[2, 3], [79, 69], [0, 0]], 16, sp, cp)
+    assert d.shape == (3, 16)
+
+
+# ---------------------------------------------------------------------------------------------------
+# IT:alg/filter/convolve/*, IT:alg/filter/blur/TestBlurImageOps.java, IT:alg/filter/derivative/TestGradientSobel.java
+# ---------------------------------------------------------------------------------------------------
+def test_convolution_equivalences(orc):
+    rand = orc.JavaRandom(234)
+    img = rand.fillUniform(orc.Gray(35, 28), 0, 50)
+    A = img.array().astype(np.float64)
+    for r in (1, 2, 3, 5, 6):
+        k = orc.gaussian1d_f32(-1, r)
+        assert len(k) == 2 * r + 1 and abs(float(np.sum(k)) - 1) < 1e-6
+        h = orc.conv("h", k, r, img).array()
+        v = orc.conv("v", k, r, img).array()
+        eh = np.zeros_like(A); ev = np.zeros_like(A)
+        for i in range(2 * r + 1):
+            eh[:, r:35 - r] += A[:, i:35 - 2 * r + i] * float(k[i])
+            ev[r:28 - r, :] += A[i:28 - 2 * r + i, :] * float(k[i])
+        assert np.max(np.abs(h - eh)) < 1e-3 and np.max(np.abs(v - ev)) < 1e-3
+        # normalised border: interior equals no-border result; border = renormalised partial sums
+        nh = orc.conv("norm_h", k, r, img).array()
+        assert np.array_equal(nh[:, r:35 - r], h[:, r:35 - r])
+        x = 0
+        part = sum(A[3, j] * float(k[j - x + r]) for j in range(0, r + 1)) / sum(float(k[j - x + r]) for j in range(0, r + 1))
+        assert abs(nh[3, 0] - part) < 1e-3
+        # Gaussian blur = normalised H then V; constant image stays constant
+    flat = orc.Gray.from_array(np.full((28, 35), 7, np.float32))
+    assert np.max(np.abs(orc.gaussian_blur(flat, -1, 2).array() - 7)) < 1e-5
+    b = orc.gaussian_blur(img, -1, 2)
+    k = orc.gaussian1d_f32(-1, 2)
+    assert np.array_equal(b.array(), orc.conv("norm_v", k, 2, orc.conv("norm_h", k, 2, img)).array())
+
+
+def test_gradients_equal_kernel_convolution(orc):
+    rand = orc.JavaRandom(234)
+    img = rand.fillUniform(orc.Gray(31, 26), 0, 50)
+    A = img.array().astype(np.float64)
+    dx, dy = orc.gradient("sobel", img)
+    kx = np.array([[-0.25, 0, 0.25], [-0.5, 0, 0.5], [-0.25, 0, 0.25]]); ky = kx.T
+    ex = np.zeros_like(A); ey = np.zeros_like(A)
+    for i in range(3):
+        for j in range(3):
+            ex[1:-1, 1:-1] += A[i:26 - 2 + i, j:31 - 2 + j] * kx[i, j]
+            ey[1:-1, 1:-1] += A[i:26 - 2 + i, j:31 - 2 + j] * ky[i, j]
+    assert np.max(np.abs(dx.array() - ex)) < 1e-4 and np.max(np.abs(dy.array() - ey)) < 1e-4
+    tx, ty = orc.gradient("three", img)
+    assert np.allclose(tx.array()[1:-1, 1:-1], (A[1:-1, 2:] - A[1:-1, :-2]) * 0.5, atol=1e-5)
+    assert np.allclose(ty.array()[1:-1, 1:-1], (A[2:, 1:-1] - A[:-2, 1:-1]) * 0.5, atol=1e-5)
+    # zero-value border policy fills the frame
+    bx, by = orc.gradient("sobel", img, border_zero=True)
+    Ap = np.pad(A, 1)
+    e = sum(Ap[0 + i, 0 + j] * kx[i, j] for i in range(3) for j in range(3))
+    assert abs(bx.array()[0, 0] - e) < 1e-4
+    assert np.array_equal(bx.array()[1:-1, 1:-1], dx.array()[1:-1, 1:-1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Gaussian tables used by orientation / SURF (I:factory/filter/kernel/FactoryKernelGaussian.java) -- "sums to one" property
+# ---------------------------------------------------------------------------------------------------
+def test_gaussian_tables(orc):
+    w = orc.gaussian2d_f64(-1, 8)
+    assert w.shape == (17, 17) and abs(w.sum() - 1) < 1e-12 and np.allclose(w, w.T) and w[8, 8] == w.max()
+    g = orc.gaussian_width(2.5, 4)
+    assert g.shape == (4, 4) and abs(g.sum() - 1) < 1e-12 and np.allclose(g, g[::-1, ::-1])
+    g9 = orc.gaussian_width(2.5, 9)
+    assert g9.shape == (9, 9) and abs(g9.sum() - 1) < 1e-12 and g9[4, 4] == g9.max()
+    g20 = orc.gaussian_width(4.5, 20)
+    assert g20.shape == (20, 20) and abs(g20.sum() - 1) < 1e-12
