@@ -1,0 +1,760 @@
+"""Host-side mirror of the reference's interfaces for the detect -> describe -> associate path, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow the Java reference (waicool20/BoofCV 0.35-SNAPSHOT) so that the parity
+tests read like the reference's own tests; every call runs hand-written HIP kernels in libboofhip.so on an MI355X.
+
+    F: = main/boofcv-feature/src/main/java/boofcv/   I: = main/boofcv-ip/src/main/java/boofcv/   T: = main/boofcv-types/src/main/java/boofcv/
+
+  FactoryDetectDescribe.surfStable / surfFast   F:factory/feature/detdesc/FactoryDetectDescribe.java:118-135,209-226
+  DetectDescribePoint                            F:abst/feature/detdesc/DetectDescribePoint.java:32-46
+  FactoryAssociation.greedy / AssociateDescription   F:factory/feature/associate/FactoryAssociation.java:51-65 ; F:abst/feature/associate/AssociateDescription.java:42-61
+  BOverride* hooks (static op classes)           I:alg/filter/convolve/BOverrideConvolveImage.java:37-83 etc.
+
+Errors: BHIP_ERR_INVALID -> IllegalArgumentException, everything else -> RuntimeError (which is what a BOverride hook throws to make the
+reference fall back to its Java code).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+Double_MAX_VALUE = 1.7976931348623157e308
+Float_MAX_VALUE = float(np.finfo(np.float32).max)
+
+
+class IllegalArgumentException(ValueError):
+    pass
+
+
+def _check(ctx, status):
+    if status == _lib.BHIP_OK:
+        return
+    msg = _lib.load().bhip_last_error(ctx._h if ctx is not None else None)
+    msg = msg.decode(errors="replace") if msg else ""
+    if status == _lib.BHIP_ERR_INVALID:
+        raise IllegalArgumentException(msg or "invalid argument")
+    raise RuntimeError("boofhip status %d: %s" % (status, msg))
+
+
+class Context:
+    """bhip_ctx: one per host thread per device."""
+    _default = {}
+
+    def __init__(self, device=0, stream=None):
+        L = _lib.load()
+        h = C.c_void_p()
+        if stream is None:
+            st = L.bhip_ctx_create(device, C.byref(h))
+        else:
+            st = L.bhip_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h))
+        if st != _lib.BHIP_OK:
+            raise RuntimeError("bhip_ctx_create(device=%d) failed with status %d: no usable MI355X? (there is no CPU fallback)" % (device, st))
+        self._h = h
+        self.device = device
+
+    def synchronize(self):
+        _check(self, _lib.load().bhip_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.load().bhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @classmethod
+    def default(cls, device=0):
+        if device not in cls._default:
+            cls._default[device] = Context(device)
+        return cls._default[device]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# data types
+# ------------------------------------------------------------------------------------------------------------------
+class GrayF32:
+    """T:struct/image/GrayF32.java:30 / ImageBase.java:34-52: pixel (x,y) = data[startIndex + y*stride + x]."""
+
+    def __init__(self, width=0, height=0, data=None, startIndex=0, stride=None):
+        self.width, self.height = int(width), int(height)
+        self.stride = int(width if stride is None else stride)
+        self.startIndex = int(startIndex)
+        if data is None:
+            data = np.zeros(self.startIndex + self.stride * self.height, dtype=np.float32)
+        if data.dtype != np.float32 or not data.flags["C_CONTIGUOUS"] or data.ndim != 1:
+            raise IllegalArgumentException("data must be a contiguous 1-D float32 array")
+        self.data = data
+
+    @staticmethod
+    def wrap(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return GrayF32(a.shape[1], a.shape[0], a.reshape(-1))
+
+    def reshape(self, width, height):
+        if width * height > self.data.size or self.startIndex != 0:
+            self.data = np.zeros(width * height, dtype=np.float32)
+            self.startIndex = 0
+        self.width, self.height, self.stride = int(width), int(height), int(width)
+
+    def subimage(self, x0, y0, x1, y1):
+        return GrayF32(x1 - x0, y1 - y0, self.data, self.startIndex + y0 * self.stride + x0, self.stride)
+
+    def array(self):
+        return np.lib.stride_tricks.as_strided(self.data[self.startIndex:], shape=(self.height, self.width), strides=(4 * self.stride, 4))
+
+    def get(self, x, y):
+        if not (0 <= x < self.width and 0 <= y < self.height):
+            raise IndexError("Requested pixel is out of bounds: %d %d" % (x, y))  # ImageAccessException
+        return float(self.data[self.startIndex + y * self.stride + x])
+
+    def set(self, x, y, v):
+        if not (0 <= x < self.width and 0 <= y < self.height):
+            raise IndexError("Requested pixel is out of bounds: %d %d" % (x, y))
+        self.data[self.startIndex + y * self.stride + x] = v
+
+    def _p(self):
+        return self.data.ctypes.data_as(C.POINTER(C.c_float))
+
+
+@dataclass
+class Point2D_F64:
+    x: float = 0.0
+    y: float = 0.0
+
+
+@dataclass
+class Point2D_I16:
+    x: int = 0
+    y: int = 0
+
+
+class TupleDesc_F64:
+    """F:struct/feature/TupleDesc_F64.java:30"""
+
+    def __init__(self, numFeatures=0, value=None):
+        self.value = np.zeros(numFeatures, dtype=np.float64) if value is None else np.asarray(value, dtype=np.float64)
+
+    def size(self):
+        return len(self.value)
+
+    def setTo(self, src):
+        self.value = np.array(src.value, dtype=np.float64)
+
+
+class BrightFeature(TupleDesc_F64):
+    """F:struct/feature/BrightFeature.java:32: SURF descriptor + sign of the Laplacian."""
+
+    def __init__(self, numFeatures=0, value=None, white=False):
+        super().__init__(numFeatures, value)
+        self.white = bool(white)
+
+    def setTo(self, src):
+        super().setTo(src)
+        self.white = getattr(src, "white", False)
+
+
+class TupleDesc_B:
+    """F:struct/feature/TupleDesc_B.java:27-40: numBits packed into int32 words."""
+
+    def __init__(self, numBits, data=None):
+        self.numBits = int(numBits)
+        n = (self.numBits + 31) // 32
+        self.data = np.zeros(n, dtype=np.int32) if data is None else np.asarray(data, dtype=np.int32)
+
+
+@dataclass
+class AssociatedIndex:
+    """F:struct/feature/AssociatedIndex.java:30-34"""
+    src: int = 0
+    dst: int = 0
+    fitScore: float = 0.0
+
+
+class MatchScoreType:
+    NORM_ERROR = "NORM_ERROR"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configuration (public mutable fields, null => defaults, as in the reference)
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class ConfigFastHessian:
+    """F:abst/feature/detect/interest/ConfigFastHessian.java:33-70"""
+    detectThreshold: float = 1.0
+    extractRadius: int = 2
+    maxFeaturesPerScale: int = -1
+    initialSampleSize: int = 1
+    initialSize: int = 9
+    numberScalesPerOctave: int = 4
+    numberOfOctaves: int = 4
+    scaleStepSize: int = 6
+
+    def _c(self):
+        return _lib.FhCfg(self.detectThreshold, self.extractRadius, self.maxFeaturesPerScale, self.initialSampleSize, self.initialSize,
+                          self.numberScalesPerOctave, self.numberOfOctaves, self.scaleStepSize)
+
+
+class ConfigSurfDescribe:
+    """F:abst/feature/describe/ConfigSurfDescribe.java:34-78"""
+
+    @dataclass
+    class Speed:
+        widthLargeGrid: int = 4
+        widthSubRegion: int = 5
+        widthSample: int = 3
+        useHaar: bool = False
+        weightSigma: float = 4.5
+
+    @dataclass
+    class Stability:
+        widthLargeGrid: int = 4
+        widthSubRegion: int = 5
+        widthSample: int = 3
+        useHaar: bool = False
+        overLap: int = 2
+        sigmaLargeGrid: float = 2.5
+        sigmaSubRegion: float = 2.5
+
+
+@dataclass
+class ConfigSlidingIntegral:
+    """F:abst/feature/orientation/ConfigSlidingIntegral.java:34-54"""
+    objectRadiusToScale: float = 0.5
+    samplePeriod: float = 0.65
+    windowSize: float = math.pi / 3.0
+    radius: int = 8
+    weightSigma: float = -1.0
+    sampleWidth: int = 6
+
+
+@dataclass
+class ConfigAverageIntegral:
+    """F:abst/feature/orientation/ConfigAverageIntegral.java:34-51"""
+    objectRadiusToScale: float = 0.5
+    radius: int = 6
+    samplePeriod: float = 1.0
+    sampleWidth: int = 6
+    weightSigma: float = -1.0
+
+
+@dataclass
+class ConfigExtract:
+    """F:abst/feature/detect/extract/ConfigExtract.java:32-56"""
+    radius: int = 1
+    threshold: float = 0.0
+    ignoreBorder: int = 0
+    useStrictRule: bool = True
+    detectMinimums: bool = False
+    detectMaximums: bool = True
+
+    def checkValidity(self):
+        if self.radius <= 0:
+            raise IllegalArgumentException("Search radius must be >= 1")
+        if self.ignoreBorder < 0:
+            raise IllegalArgumentException("Ignore border must be >= 0 ")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# detect + describe
+# ------------------------------------------------------------------------------------------------------------------
+class DetectDescribePoint:
+    """DetectDescribePoint<GrayF32,BrightFeature> backed by bhip_surf (WrapDetectDescribeSurf.java:47-159).
+
+    Results are recycled on the next detect(), instances are not thread safe -- both as in the reference.
+    detectBatch() is the batched extension (one launch sequence for many frames)."""
+
+    def __init__(self, stable, configDetector, configDescribe, configOrientation, ctx=None):
+        self.ctx = ctx or Context.default()
+        L = _lib.load()
+        fh = (configDetector or ConfigFastHessian())._c()
+        if stable:
+            d = configDescribe or ConfigSurfDescribe.Stability()
+            sd = _lib.SurfCfg(d.widthLargeGrid, d.widthSubRegion, d.widthSample, 4.5, d.overLap, d.sigmaLargeGrid, d.sigmaSubRegion)
+            o = configOrientation or ConfigSlidingIntegral()
+            oc = _lib.OriCfg(o.objectRadiusToScale, o.samplePeriod, o.windowSize, o.radius, o.weightSigma, o.sampleWidth)
+        else:
+            d = configDescribe or ConfigSurfDescribe.Speed()
+            sd = _lib.SurfCfg(d.widthLargeGrid, d.widthSubRegion, d.widthSample, d.weightSigma, 2, 2.5, 2.5)
+            o = configOrientation or ConfigAverageIntegral()
+            oc = _lib.OriCfg(o.objectRadiusToScale, o.samplePeriod, 0.0, o.radius, o.weightSigma, o.sampleWidth)
+        if d.useHaar:
+            raise RuntimeError("useHaar=true is not implemented on the GPU (use the Java path)")
+        h = C.c_void_p()
+        _check(self.ctx, L.bhip_surf_create(self.ctx._h, C.byref(fh), C.byref(sd), C.byref(oc), 1 if stable else 0, C.byref(h)))
+        self._h = h
+        self._dof = L.bhip_surf_dof(h)
+        self._batch = 0
+        self._image = 0
+        self._cache = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().bhip_surf_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # --- DescriptorInfo
+    def createDescription(self):
+        return BrightFeature(self._dof)
+
+    def getDescriptionType(self):
+        return BrightFeature
+
+    # --- detection
+    def detect(self, input):
+        self.detectBatch([input])
+
+    def detectBatch(self, images):
+        if not images:
+            raise IllegalArgumentException("empty batch")
+        w, h = images[0].width, images[0].height
+        for im in images:
+            if im.width != w or im.height != h:
+                raise IllegalArgumentException("all images of a batch must have the same shape")
+        n = len(images)
+        ptrs = (C.POINTER(C.c_float) * n)(*[im._p() for im in images])
+        starts = (C.c_int * n)(*[im.startIndex for im in images])
+        strides = (C.c_int * n)(*[im.stride for im in images])
+        self._cache = {}
+        self._batch = 0
+        _check(self.ctx, _lib.load().bhip_surf_detect_f32(self._h, ptrs, starts, strides, w, h, n))
+        self._batch = n
+        self._image = 0
+
+    def detectDevice(self, dev_ptr, imageStride, stride, width, height, batch):
+        """Batch already resident in HBM (bench path): dev_ptr is a device address of float32 pixels."""
+        self._cache = {}
+        self._batch = 0
+        _check(self.ctx, _lib.load().bhip_surf_detect_dev_f32(self._h, C.c_void_p(dev_ptr), imageStride, stride, width, height, batch))
+        self._batch = batch
+        self._image = 0
+
+    def selectImage(self, image):
+        """Which image of the last batch the index-based getters refer to (0 for the single-image reference call)."""
+        if not (0 <= image < self._batch):
+            raise IllegalArgumentException("image index out of range")
+        self._image = image
+
+    def _results(self, image=None):
+        image = self._image if image is None else image
+        if image not in self._cache:
+            L = _lib.load()
+            n = C.c_int(0)
+            _check(self.ctx, L.bhip_surf_count(self._h, image, C.byref(n)))
+            n = n.value
+            xys = np.zeros((n, 3)); ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); desc = np.zeros((n, self._dof))
+            if n:
+                _check(self.ctx, L.bhip_surf_fetch(self._h, image, xys.ctypes.data_as(_lib._dp), ang.ctypes.data_as(_lib._dp),
+                                                   white.ctypes.data_as(_lib._u8p), desc.ctypes.data_as(_lib._dp)))
+            self._cache[image] = (xys, ang, white, desc)
+        return self._cache[image]
+
+    def totalFeatures(self):
+        n = C.c_longlong(0)
+        _check(self.ctx, _lib.load().bhip_surf_total(self._h, C.byref(n)))
+        return n.value
+
+    def deviceView(self, image):
+        """(dev_desc_ptr, dev_keypoint_ptr, dev_white_ptr, n) of image `image` -- valid until the next detect."""
+        d, k, w, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+        _check(self.ctx, _lib.load().bhip_surf_dev_view(self._h, image, C.byref(d), C.byref(k), C.byref(w), C.byref(n)))
+        return d.value, k.value, w.value, n.value
+
+    def describePoints(self, xy_scale, image=0):
+        """computeDescriptors() for a caller-supplied point list on the integral image of the last detect."""
+        pts = np.ascontiguousarray(xy_scale, dtype=np.float64).reshape(-1, 3)
+        n = len(pts)
+        ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); desc = np.zeros((n, self._dof))
+        _check(self.ctx, _lib.load().bhip_surf_describe_points(self._h, image, pts.ctypes.data_as(_lib._dp), n, ang.ctypes.data_as(_lib._dp),
+                                                              white.ctypes.data_as(_lib._u8p), desc.ctypes.data_as(_lib._dp)))
+        return ang, white, desc
+
+    def fetchIntegral(self, image, width, height):
+        out = np.zeros((height, width), dtype=np.float32)
+        _check(self.ctx, _lib.load().bhip_surf_fetch_integral(self._h, image, out.ctypes.data_as(_lib._fp)))
+        return out
+
+    # --- InterestPointDetector / FoundPointSO
+    def getNumberOfFeatures(self):
+        return len(self._results()[0])
+
+    def getLocation(self, featureIndex):
+        x = self._results()[0][featureIndex]
+        return Point2D_F64(float(x[0]), float(x[1]))
+
+    def getRadius(self, featureIndex):
+        return float(self._results()[0][featureIndex][2]) * 2.0  # BoofDefaults.SURF_SCALE_TO_RADIUS
+
+    def getOrientation(self, featureIndex):
+        return float(self._results()[1][featureIndex])
+
+    def getDescription(self, index):
+        r = self._results()
+        return BrightFeature(self._dof, r[3][index], bool(r[2][index]))
+
+    def hasScale(self):
+        return True
+
+    def hasOrientation(self):
+        return True
+
+
+class FactoryDetectDescribe:
+    @staticmethod
+    def surfFast(configDetector=None, configDesc=None, configOrientation=None, imageType=GrayF32, ctx=None):
+        if imageType is not GrayF32:
+            raise RuntimeError("only GrayF32 is implemented on the GPU (use the Java path)")
+        return DetectDescribePoint(False, configDetector, configDesc, configOrientation, ctx)
+
+    @staticmethod
+    def surfStable(configDetector=None, configDescribe=None, configOrientation=None, imageType=GrayF32, ctx=None):
+        if imageType is not GrayF32:
+            raise RuntimeError("only GrayF32 is implemented on the GPU (use the Java path)")
+        return DetectDescribePoint(True, configDetector, configDescribe, configOrientation, ctx)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# association
+# ------------------------------------------------------------------------------------------------------------------
+class ScoreAssociateEuclideanSq_F64:
+    """F:abst/feature/associate/ScoreAssociateEuclideanSq_F64.java -> DescriptorDistance.euclideanSq"""
+    kind, sqrt = "l2", 0
+
+    def getScoreType(self):
+        return MatchScoreType.NORM_ERROR
+
+
+class ScoreAssociateEuclidean_F64:
+    kind, sqrt = "l2", 1
+
+    def getScoreType(self):
+        return MatchScoreType.NORM_ERROR
+
+
+class ScoreAssociateHamming_B:
+    kind, sqrt = "hamming", 0
+
+    def getScoreType(self):
+        return MatchScoreType.NORM_ERROR
+
+
+class AssociateDescription:
+    """WrapAssociateGreedy (F:abst/feature/associate/WrapAssociateGreedy.java:73-123) over AssociateGreedy on the GPU."""
+
+    def __init__(self, score, maxError, backwardsValidation, ctx=None):
+        self.ctx = ctx or Context.default()
+        self.score = score
+        self.maxFitError = float(maxError)
+        self.backwardsValidation = bool(backwardsValidation)
+        self.listSrc = None
+        self.listDst = None
+        self.matches = []
+        self.unassocSrc = []
+        self._pairs = np.zeros(0, dtype=np.int32)
+        self._fit = np.zeros(0)
+
+    def setSource(self, listSrc):
+        self.listSrc = listSrc
+
+    def setDestination(self, listDst):
+        self.listDst = listDst
+
+    @staticmethod
+    def _pack(lst, kind):
+        if isinstance(lst, np.ndarray):
+            return np.ascontiguousarray(lst, dtype=np.float64 if kind == "l2" else np.int32)
+        if len(lst) == 0:
+            return np.zeros((0, 1), dtype=np.float64 if kind == "l2" else np.int32)
+        if kind == "l2":
+            return np.ascontiguousarray(np.stack([np.asarray(d.value, dtype=np.float64) for d in lst]))
+        return np.ascontiguousarray(np.stack([np.asarray(d.data, dtype=np.int32) for d in lst]))
+
+    def associate(self):
+        if self.listSrc is None:
+            raise IllegalArgumentException("source features not specified")
+        if self.listDst is None:
+            raise IllegalArgumentException("destination features not specified")
+        kind = self.score.kind
+        src = self._pack(self.listSrc, kind)
+        dst = self._pack(self.listDst, kind)
+        ns, nd = len(src), len(dst)
+        length = src.shape[1] if ns else (dst.shape[1] if nd else 1)
+        if ns and nd and src.shape[1] != dst.shape[1]:
+            raise IllegalArgumentException("descriptor lengths differ")
+        pairs = np.full(ns, -1, dtype=np.int32)
+        fit = np.full(ns, self.maxFitError, dtype=np.float64)
+        L = _lib.load()
+        if ns:
+            if kind == "l2":
+                _check(self.ctx, L.bhip_assoc_l2_f64(self.ctx._h, src.ctypes.data_as(_lib._dp), ns, dst.ctypes.data_as(_lib._dp), nd, length,
+                                                     self.maxFitError, int(self.backwardsValidation), self.score.sqrt,
+                                                     pairs.ctypes.data_as(_lib._ip), fit.ctypes.data_as(_lib._dp)))
+            else:
+                _check(self.ctx, L.bhip_assoc_hamming(self.ctx._h, src.ctypes.data_as(_lib._i32p), ns, dst.ctypes.data_as(_lib._i32p), nd, length,
+                                                      self.maxFitError, int(self.backwardsValidation), pairs.ctypes.data_as(_lib._ip),
+                                                      fit.ctypes.data_as(_lib._dp)))
+        self._pairs, self._fit, self._nd = pairs, fit, nd
+        self.matches = [AssociatedIndex(i, int(pairs[i]), float(fit[i])) for i in range(ns) if pairs[i] >= 0]
+        self.unassocSrc = [i for i in range(ns) if pairs[i] < 0]
+
+    def getPairs(self):
+        return self._pairs
+
+    def getFitQuality(self):
+        return self._fit
+
+    def getMatches(self):
+        return self.matches
+
+    def getUnassociatedSource(self):
+        return self.unassocSrc
+
+    def getUnassociatedDestination(self):
+        # FindUnassociated.checkDestination (F:alg/feature/associate/FindUnassociated.java:56-72)
+        matched = np.zeros(self._nd, dtype=bool)
+        for m in self.matches:
+            matched[m.dst] = True
+        return [i for i in range(self._nd) if not matched[i]]
+
+    def setMaxScoreThreshold(self, score):
+        self.maxFitError = float(score)
+
+    def getScoreType(self):
+        return self.score.getScoreType()
+
+    def uniqueSource(self):
+        return True
+
+    def uniqueDestination(self):
+        return self.backwardsValidation
+
+
+class FactoryAssociation:
+    @staticmethod
+    def greedy(score, maxError, backwardsValidation, ctx=None):
+        return AssociateDescription(score, maxError, backwardsValidation, ctx)
+
+    @staticmethod
+    def defaultScore(tupleType):
+        """F:factory/feature/associate/FactoryAssociation.java:141-156"""
+        if issubclass(tupleType, TupleDesc_F64):
+            return ScoreAssociateEuclideanSq_F64()
+        if tupleType is TupleDesc_B:
+            return ScoreAssociateHamming_B()
+        raise IllegalArgumentException("Unknown tuple type: %s" % tupleType)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# static op classes = what the BOverride* hooks replace
+# ------------------------------------------------------------------------------------------------------------------
+def _ctx(ctx):
+    return ctx or Context.default()
+
+
+class IntegralImageOps:
+    @staticmethod
+    def transform(input, transformed=None, ctx=None):
+        """GIntegralImageOps.transform (I:alg/transform/ii/GIntegralImageOps.java:55-70)"""
+        ctx = _ctx(ctx)
+        if transformed is None:
+            transformed = GrayF32(input.width, input.height)
+        elif transformed.width != input.width or transformed.height != input.height:
+            transformed.reshape(input.width, input.height)
+        _check(ctx, _lib.load().bhip_integral_f32(ctx._h, input._p(), input.startIndex, input.stride, input.width, input.height, transformed._p(),
+                                                  transformed.startIndex, transformed.stride))
+        return transformed
+
+
+class IntegralImageFeatureIntensity:
+    @staticmethod
+    def hessian(integral, skip, size, intensity, ctx=None):
+        """F:alg/feature/detect/intensity/IntegralImageFeatureIntensity.java:43-56; intensity must be (width/skip) x (height/skip)."""
+        ctx = _ctx(ctx)
+        _check(ctx, _lib.load().bhip_hessian_f32(ctx._h, integral._p(), integral.startIndex, integral.stride, integral.width, integral.height, skip, size,
+                                                 intensity._p(), intensity.startIndex, intensity.stride))
+
+
+class NonMaxSuppression:
+    """FactoryFeatureExtractor.nonmax(config) -> WrapperNonMaximumBlock(NonMaxBlock(NonMaxBlockSearchStrict.Max))
+    (F:factory/feature/detect/extract/FactoryFeatureExtractor.java:63-102).  Only the strict, maxima-only extractor runs on the GPU;
+    anything else raises RuntimeError, which is the BOverride convention for "use the Java code"."""
+
+    def __init__(self, config, ctx=None):
+        config = config or ConfigExtract()
+        config.checkValidity()
+        if not config.useStrictRule or config.detectMinimums or not config.detectMaximums:
+            raise RuntimeError("only the strict maxima extractor is implemented on the GPU")
+        self.ctx = _ctx(ctx)
+        self.radius, self.threshold, self.border = config.radius, config.threshold, config.ignoreBorder
+
+    def process(self, intensity, candidateMin=None, candidateMax=None, foundMin=None, foundMax=None):
+        cap = max(1, ((intensity.width + self.radius) // (self.radius + 1)) * ((intensity.height + self.radius) // (self.radius + 1)))
+        xy = np.zeros((cap, 2), dtype=np.int16)
+        n = C.c_int(0)
+        _check(self.ctx, _lib.load().bhip_nonmax_block_f32(self.ctx._h, intensity._p(), intensity.startIndex, intensity.stride, intensity.width,
+                                                          intensity.height, self.radius, self.threshold, self.border, xy.ctypes.data_as(_lib._i16p), cap,
+                                                          C.byref(n)))
+        out = [Point2D_I16(int(x), int(y)) for x, y in xy[:n.value]]
+        if foundMax is not None:
+            del foundMax[:]
+            foundMax.extend(out)
+        return out
+
+    def getSearchRadius(self): return self.radius
+    def setSearchRadius(self, r): self.radius = r
+    def getIgnoreBorder(self): return self.border
+    def setIgnoreBorder(self, b): self.border = b
+    def getThresholdMaximum(self): return self.threshold
+    def setThresholdMaximum(self, t): self.threshold = t
+    def getUsesCandidates(self): return False
+    def canDetectMaximums(self): return True
+    def canDetectMinimums(self): return False
+
+
+class FactoryFeatureExtractor:
+    @staticmethod
+    def nonmax(config=None, ctx=None):
+        return NonMaxSuppression(config, ctx)
+
+
+class FastHessianFeatureDetector:
+    """FactoryInterestPointAlgs.fastHessian(config).detect(integral) (F:alg/feature/detect/interest/FastHessianFeatureDetector.java:156-188)"""
+
+    def __init__(self, config=None, ctx=None):
+        self.config = config or ConfigFastHessian()
+        self.ctx = _ctx(ctx)
+        self.foundPoints = np.zeros((0, 3))
+
+    def detect(self, integral):
+        cfg = self.config._c()
+        cap = 1 << 15
+        while True:
+            out = np.zeros((cap, 3))
+            n = C.c_int(0)
+            _check(self.ctx, _lib.load().bhip_fh_detect_f32(self.ctx._h, C.byref(cfg), integral._p(), integral.startIndex, integral.stride, integral.width,
+                                                           integral.height, out.ctypes.data_as(_lib._dp), cap, C.byref(n)))
+            if n.value <= cap:
+                self.foundPoints = out[:n.value].copy()
+                return
+            cap = n.value
+
+    def getFoundPoints(self):
+        return self.foundPoints
+
+
+@dataclass
+class Kernel1D_F32:
+    """T:struct/convolve/Kernel1D_F32.java: data, width, offset (origin index; width/2 by default)"""
+    data: np.ndarray
+    width: int = 0
+    offset: int = -1
+
+    def __post_init__(self):
+        self.data = np.ascontiguousarray(self.data, dtype=np.float32)
+        self.width = len(self.data)
+        if self.offset < 0:
+            self.offset = self.width // 2
+
+
+def _conv(fn, kernel, src, dst, ctx):
+    ctx = _ctx(ctx)
+    if dst.width != src.width or dst.height != src.height:
+        raise IllegalArgumentException("Image shapes do not match")  # InputSanityCheck.checkSameShape
+    _check(ctx, fn(ctx._h, kernel.data.ctypes.data_as(_lib._fp), kernel.width, kernel.offset, src._p(), src.startIndex, src.stride, src.width, src.height,
+                   dst._p(), dst.startIndex, dst.stride))
+
+
+class ConvolveImageNoBorder:
+    """BOverrideConvolveImage.horizontal/vertical targets (I:alg/filter/convolve/ConvolveImageNoBorder.java:53-77)"""
+
+    @staticmethod
+    def horizontal(kernel, input, output, ctx=None):
+        _conv(_lib.load().bhip_conv_h_f32, kernel, input, output, ctx)
+
+    @staticmethod
+    def vertical(kernel, input, output, ctx=None):
+        _conv(_lib.load().bhip_conv_v_f32, kernel, input, output, ctx)
+
+
+class ConvolveImageNormalized:
+    """BOverrideConvolveImageNormalized targets (I:alg/filter/convolve/ConvolveImageNormalized.java:48-93)"""
+
+    @staticmethod
+    def horizontal(kernel, src, dst, ctx=None):
+        _conv(_lib.load().bhip_conv_norm_h_f32, kernel, src, dst, ctx)
+
+    @staticmethod
+    def vertical(kernel, src, dst, ctx=None):
+        _conv(_lib.load().bhip_conv_norm_v_f32, kernel, src, dst, ctx)
+
+
+class BlurImageOps:
+    @staticmethod
+    def gaussian(input, output, sigma, radius, storage=None, ctx=None):
+        """BOverrideBlurImageOps.gaussian target (I:alg/filter/blur/BlurImageOps.java:406-425)"""
+        ctx = _ctx(ctx)
+        if output is None:
+            output = GrayF32(input.width, input.height)
+        _check(ctx, _lib.load().bhip_gaussian_f32(ctx._h, input._p(), input.startIndex, input.stride, input.width, input.height, float(sigma), int(radius),
+                                                  output._p(), output.startIndex, output.stride))
+        return output
+
+
+class _Gradient:
+    fn = None
+
+    @classmethod
+    def process(cls, orig, derivX, derivY, border=None, ctx=None):
+        """border: None = null (frame untouched) or 0 = ImageBorderValue(0)"""
+        ctx = _ctx(ctx)
+        if border not in (None, 0):
+            raise RuntimeError("border policy not implemented on the GPU")
+        _check(ctx, getattr(_lib.load(), cls.fn)(ctx._h, orig._p(), orig.startIndex, orig.stride, orig.width, orig.height, derivX._p(), derivY._p(),
+                                                 derivX.startIndex, derivX.stride, 0 if border is None else 1))
+
+
+class GradientSobel(_Gradient):
+    """I:alg/filter/derivative/GradientSobel.java:158-173"""
+    fn = "bhip_sobel_f32"
+
+
+class GradientThree(_Gradient):
+    """I:alg/filter/derivative/GradientThree.java -> impl/GradientThree_Standard.java:40-62"""
+    fn = "bhip_three_f32"
+
+
+class DescribePointBrief:
+    """DescribePointBrief.process for a list of points (F:alg/feature/describe/DescribePointBrief.java:73-89).  As in this fork of the
+    reference, the fixed BRIEF variant samples the UNblurred image (SURVEY finding 6)."""
+
+    def __init__(self, radius, samplePoints, compare, ctx=None):
+        self.ctx = _ctx(ctx)
+        self.radius = int(radius)
+        self.samplePoints = np.ascontiguousarray(samplePoints, dtype=np.int32)
+        self.compare = np.ascontiguousarray(compare, dtype=np.int32)
+        self.image = None
+
+    def setImage(self, image):
+        self.image = image
+
+    def processAll(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        n, npts = len(xy), len(self.compare)
+        out = np.zeros((n, (npts + 31) // 32), dtype=np.int32)
+        im = self.image
+        _check(self.ctx, _lib.load().bhip_brief_f32(self.ctx._h, im._p(), im.startIndex, im.stride, im.width, im.height, self.radius, npts,
+                                                   self.samplePoints.ctypes.data_as(_lib._i32p), self.compare.ctypes.data_as(_lib._i32p),
+                                                   xy.ctypes.data_as(_lib._dp), n, out.ctypes.data_as(_lib._i32p)))
+        return out
+
+    def process(self, c_x, c_y, feature):
+        feature.data[:] = self.processAll([[c_x, c_y]])[0]

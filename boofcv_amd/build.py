@@ -1,0 +1,62 @@
+"""Builds boofcv_amd/libboofhip.so (hand-written HIP kernels + the C ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off keeps Java's "no fused multiply-add" arithmetic in every kernel;
+fp32 divide/sqrt stay correctly rounded.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libboofhip.so")
+ARCH = "gfx950"
+
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "boofhip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-c", src, "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"), file=sys.stderr)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,295 @@
+// K6 / K7: greedy brute-force association with exact scores (fp64 sequential L2, integer Hamming).
+//
+// Reference:
+//   AssociateGreedy.associate          F:alg/feature/associate/AssociateGreedy.java:65-118
+//   DescriptorDistance.euclideanSq     F:alg/descriptor/DescriptorDistance.java:55-64   (euclidean :36-46)
+//   DescriptorDistance.hamming         F:alg/descriptor/DescriptorDistance.java:196-220
+//
+// The reference stores the whole Ns x Nd score matrix and then walks its columns.  Here the matrix is never stored:
+//   forward : per source row, arg-min over destinations with `fit <= best` (largest index among minima, inclusive threshold)
+//   backward: per destination column, top-2 over sources (min1, argmin1, min2).  Match (i -> m) survives iff i is the arg-min of
+//             column m and min2 > min1 -- exactly "no other j has W[j][m] <= W[i][m]" (AssociateGreedy.java:105-114).
+// Both passes evaluate the same sequential expression per pair, so scores are bit-identical to the reference's and to each other.
+// Each thread keeps one descriptor in registers and streams the other set through LDS (broadcast reads).  The column pass of a sharded
+// problem writes (min1, min2, argmin1) records that are all-gathered across ranks and merged by k_assoc_finish.
+#include "common.h"
+#include <cfloat>
+
+struct ColTop {
+	double min1, min2;
+	int idx1, pad;
+};
+struct RowBest {
+	double best;
+	int idx, pad;
+};
+
+#define VT 64  // vectors of the streamed set per LDS tile
+
+template <int DOF>
+struct L2Scorer {
+	typedef double elem;
+	double a[DOF];
+	int sqrtScore;
+	__device__ __forceinline__ void load(const double* __restrict__ u, int) {
+#pragma unroll
+		for (int k = 0; k < DOF; k++) a[k] = u[k];
+	}
+	__device__ __forceinline__ double score(const double* __restrict__ v, int) const {
+		double total = 0;
+#pragma unroll
+		for (int k = 0; k < DOF; k++) {
+			const double d = a[k] - v[k];
+			total += d * d;
+		}
+		return sqrtScore ? sqrt(total) : total;
+	}
+};
+// run-time length: the owned descriptor is re-read from global memory (L1/L2 resident)
+struct L2ScorerDyn {
+	typedef double elem;
+	const double* u;
+	int sqrtScore;
+	__device__ __forceinline__ void load(const double* __restrict__ p, int) { u = p; }
+	__device__ __forceinline__ double score(const double* __restrict__ v, int n) const {
+		double total = 0;
+		for (int k = 0; k < n; k++) {
+			const double d = u[k] - v[k];
+			total += d * d;
+		}
+		return sqrtScore ? sqrt(total) : total;
+	}
+};
+template <int WORDS>
+struct HamScorer {
+	typedef int elem;
+	int a[WORDS];
+	int sqrtScore;
+	__device__ __forceinline__ void load(const int* __restrict__ u, int) {
+#pragma unroll
+		for (int k = 0; k < WORDS; k++) a[k] = u[k];
+	}
+	__device__ __forceinline__ double score(const int* __restrict__ v, int) const {
+		int s = 0;
+#pragma unroll
+		for (int k = 0; k < WORDS; k++) s += __popc((unsigned)(a[k] ^ v[k]));
+		return (double)s;
+	}
+};
+struct HamScorerDyn {
+	typedef int elem;
+	const int* u;
+	int sqrtScore;
+	__device__ __forceinline__ void load(const int* __restrict__ p, int) { u = p; }
+	__device__ __forceinline__ double score(const int* __restrict__ v, int n) const {
+		int s = 0;
+		for (int k = 0; k < n; k++) s += __popc((unsigned)(u[k] ^ v[k]));
+		return (double)s;
+	}
+};
+
+// One thread owns vector `ui` of set U and scans vectors [v0, v1) of set V.
+//   COLMODE = false: U = sources,      V = destinations -> RowBest partial  (out[split][ui])
+//   COLMODE = true : U = destinations, V = sources      -> ColTop  partial  (out[split][ui]), idx = vBase + v
+template <class Scorer, bool COLMODE>
+__global__ __launch_bounds__(256) void k_assoc_scan(const typename Scorer::elem* __restrict__ U, int nU, const typename Scorer::elem* __restrict__ V, int nV,
+													 int len, int vPerSplit, int vBase, double maxErr, int sqrtScore, void* __restrict__ outRaw) {
+	typedef typename Scorer::elem elem;
+	extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+	elem* tile = (elem*)ldsRaw;
+	const int ui = blockIdx.x * blockDim.x + threadIdx.x;
+	const int split = blockIdx.y;
+	const int v0 = split * vPerSplit;
+	const int v1 = min(nV, v0 + vPerSplit);
+	const bool active = ui < nU;
+	Scorer sc;
+	sc.sqrtScore = sqrtScore;
+	sc.load(U + (long long)(active ? ui : 0) * len, len);
+
+	double best = maxErr, min1 = INFINITY, min2 = INFINITY;
+	int bestIdx = -1;
+	for (int t0 = v0; t0 < v1; t0 += VT) {
+		const int nt = min(VT, v1 - t0);
+		__syncthreads();
+		const long long base = (long long)t0 * len;
+		for (int e = threadIdx.x; e < nt * len; e += blockDim.x) tile[e] = V[base + e];
+		__syncthreads();
+		if (active) {
+			for (int j = 0; j < nt; j++) {
+				const double fit = sc.score(tile + j * len, len);
+				if (!COLMODE) {
+					if (fit <= best) { best = fit; bestIdx = t0 + j; }
+				} else {
+					if (fit < min1) { min2 = min1; min1 = fit; bestIdx = vBase + t0 + j; }
+					else if (fit < min2) { min2 = fit; }
+				}
+			}
+		}
+	}
+	if (!active) return;
+	if (!COLMODE) {
+		RowBest* out = (RowBest*)outRaw + (long long)split * nU + ui;
+		out->best = best; out->idx = bestIdx; out->pad = 0;
+	} else {
+		ColTop* out = (ColTop*)outRaw + (long long)split * nU + ui;
+		out->min1 = min1; out->min2 = min2; out->idx1 = bestIdx; out->pad = 0;
+	}
+}
+
+// merge the per-split row partials in increasing destination order (`<=` keeps the largest index among minima)
+__global__ void k_merge_rows(const RowBest* __restrict__ part, int nsplit, int ns, double maxErr, int* __restrict__ pairs, double* __restrict__ fit) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= ns) return;
+	double best = maxErr;
+	int idx = -1;
+	for (int s = 0; s < nsplit; s++) {
+		const RowBest p = part[(long long)s * ns + i];
+		if (p.idx >= 0 && p.best <= best) { best = p.best; idx = p.idx; }
+	}
+	pairs[i] = idx;
+	fit[i] = best;
+}
+
+__device__ __forceinline__ void top2Merge(double& min1, double& min2, int& idx1, const ColTop& p) {
+	if (p.min1 < min1) {
+		min2 = fmin(min1, p.min2);   // old min1 vs the newcomer's runner-up
+		min1 = p.min1;
+		idx1 = p.idx1;
+	} else {
+		if (p.min1 < min2) min2 = p.min1;
+	}
+}
+
+// merge column partials (splits of one rank, or the all-gathered records of all ranks) into one record per column
+__global__ void k_merge_cols(const ColTop* __restrict__ part, int nparts, int nd, ColTop* __restrict__ out) {
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nd) return;
+	double min1 = INFINITY, min2 = INFINITY;
+	int idx1 = -1;
+	for (int s = 0; s < nparts; s++) top2Merge(min1, min2, idx1, part[(long long)s * nd + j]);
+	ColTop r;
+	r.min1 = min1; r.min2 = min2; r.idx1 = idx1; r.pad = 0;
+	out[j] = r;
+}
+
+// backwards validation: keep (i -> m) iff i is the unique strict minimum of column m
+__global__ void k_assoc_finish(const ColTop* __restrict__ col, int ncolParts, int nd, int nsLocal, int srcBegin, int* __restrict__ pairs,
+							   double* __restrict__ fit) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nsLocal) return;
+	const int m = pairs[i];
+	if (m < 0) return;
+	double min1 = INFINITY, min2 = INFINITY;
+	int idx1 = -1;
+	for (int s = 0; s < ncolParts; s++) top2Merge(min1, min2, idx1, col[(long long)s * nd + m]);
+	if (!(idx1 == srcBegin + i && min2 > min1)) {
+		pairs[i] = -1;
+		fit[i] = DBL_MAX;
+	}
+}
+
+static int chooseSplits(int nU, int nV) {
+	const int ublocks = (nU + 255) / 256;
+	int splits = (768 + ublocks - 1) / ublocks;
+	const int maxSplits = (nV + VT - 1) / VT;
+	if (splits > maxSplits) splits = maxSplits;
+	if (splits < 1) splits = 1;
+	return splits;
+}
+
+template <class Scorer, bool COLMODE>
+static int launchScan(bhip_ctx* ctx, const typename Scorer::elem* U, int nU, const typename Scorer::elem* V, int nV, int len, int vBase, double maxErr,
+					  int sqrtScore, void* partial, int splits) {
+	int per = (nV + splits - 1) / splits;
+	per = ((per + VT - 1) / VT) * VT;
+	dim3 grid((nU + 255) / 256, splits);
+	const size_t lds = (size_t)VT * len * sizeof(typename Scorer::elem);
+	hipLaunchKernelGGL((k_assoc_scan<Scorer, COLMODE>), grid, dim3(256), lds, ctx->stream, U, nU, V, nV, len, per, vBase, maxErr, sqrtScore, partial);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+template <bool COLMODE>
+static int scanL2(bhip_ctx* ctx, const double* U, int nU, const double* V, int nV, int dof, int vBase, double maxErr, int sqrtScore, void* partial,
+				  int splits) {
+	if ((size_t)VT * dof * 8 > 64 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "descriptor too long for the LDS tile");
+	if (dof == 64) return launchScan<L2Scorer<64>, COLMODE>(ctx, U, nU, V, nV, dof, vBase, maxErr, sqrtScore, partial, splits);
+	return launchScan<L2ScorerDyn, COLMODE>(ctx, U, nU, V, nV, dof, vBase, maxErr, sqrtScore, partial, splits);
+}
+template <bool COLMODE>
+static int scanHam(bhip_ctx* ctx, const int* U, int nU, const int* V, int nV, int words, int vBase, double maxErr, void* partial, int splits) {
+	if ((size_t)VT * words * 4 > 64 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "descriptor too long for the LDS tile");
+	if (words == 16) return launchScan<HamScorer<16>, COLMODE>(ctx, U, nU, V, nV, words, vBase, maxErr, 0, partial, splits);
+	return launchScan<HamScorerDyn, COLMODE>(ctx, U, nU, V, nV, words, vBase, maxErr, 0, partial, splits);
+}
+
+static int fillUnmatched(bhip_ctx* ctx, int ns, double maxErr, int* pairs, double* fit);
+
+__global__ void k_fill_unmatched(int ns, double maxErr, int* pairs, double* fit) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < ns) { pairs[i] = -1; fit[i] = maxErr; }
+}
+static int fillUnmatched(bhip_ctx* ctx, int ns, double maxErr, int* pairs, double* fit) {
+	if (ns <= 0) return BHIP_OK;
+	hipLaunchKernelGGL(k_fill_unmatched, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, ns, maxErr, pairs, fit);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// phase 1 of the (possibly sharded) association; colTop receives one merged record per destination column (may be null when !needCols)
+template <class E>
+static int phase1(bhip_ctx* ctx, bool hamming, const E* src, int nsLocal, int srcBegin, const E* dst, int nd, int len, double maxErr, int sqrtScore,
+				  int* pairs, double* fit, ColTop* colTop, DevBuf& work) {
+	if (nsLocal < 0 || nd < 0 || len <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "negative size");
+	if (nd == 0 || nsLocal == 0) {
+		BHIP_TRY(fillUnmatched(ctx, nsLocal, maxErr, pairs, fit));
+		if (colTop && nd > 0) {
+			// no local rows: every column record is empty
+			const int rs = 1;
+			BHIP_TRY(work.reserve(ctx, sizeof(ColTop)));
+			(void)rs;
+			hipLaunchKernelGGL(k_merge_cols, dim3((nd + 255) / 256), dim3(256), 0, ctx->stream, (const ColTop*)work.p, 0, nd, colTop);
+			BHIP_HIP(ctx, hipGetLastError());
+		}
+		return BHIP_OK;
+	}
+	const int rsplits = chooseSplits(nsLocal, nd);
+	const int csplits = colTop ? chooseSplits(nd, nsLocal) : 0;
+	const size_t rowBytes = (size_t)rsplits * nsLocal * sizeof(RowBest);
+	const size_t colBytes = (size_t)csplits * nd * sizeof(ColTop);
+	BHIP_TRY(work.reserve(ctx, rowBytes + colBytes + 64));
+	RowBest* rowPart = (RowBest*)work.p;
+	ColTop* colPart = (ColTop*)((char*)work.p + ((rowBytes + 63) & ~(size_t)63));
+	if (hamming) BHIP_TRY((scanHam<false>(ctx, (const int*)src, nsLocal, (const int*)dst, nd, len, 0, maxErr, rowPart, rsplits)));
+	else BHIP_TRY((scanL2<false>(ctx, (const double*)src, nsLocal, (const double*)dst, nd, len, 0, maxErr, sqrtScore, rowPart, rsplits)));
+	hipLaunchKernelGGL(k_merge_rows, dim3((nsLocal + 255) / 256), dim3(256), 0, ctx->stream, (const RowBest*)rowPart, rsplits, nsLocal, maxErr, pairs, fit);
+	BHIP_HIP(ctx, hipGetLastError());
+	if (colTop) {
+		if (hamming) BHIP_TRY((scanHam<true>(ctx, (const int*)dst, nd, (const int*)src, nsLocal, len, srcBegin, maxErr, colPart, csplits)));
+		else BHIP_TRY((scanL2<true>(ctx, (const double*)dst, nd, (const double*)src, nsLocal, len, srcBegin, maxErr, sqrtScore, colPart, csplits)));
+		hipLaunchKernelGGL(k_merge_cols, dim3((nd + 255) / 256), dim3(256), 0, ctx->stream, (const ColTop*)colPart, csplits, nd, colTop);
+		BHIP_HIP(ctx, hipGetLastError());
+	}
+	return BHIP_OK;
+}
+
+static int phase2(bhip_ctx* ctx, const ColTop* colAll, int nranks, int nd, int nsLocal, int srcBegin, int* pairs, double* fit) {
+	if (nsLocal <= 0 || nd <= 0) return BHIP_OK;
+	hipLaunchKernelGGL(k_assoc_finish, dim3((nsLocal + 255) / 256), dim3(256), 0, ctx->stream, colAll, nranks, nd, nsLocal, srcBegin, pairs, fit);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---- entry points used by cabi.cpp ----
+int bhip_assoc_phase1_l2(bhip_ctx* ctx, const double* src, int nsLocal, int srcBegin, const double* dst, int nd, int dof, double maxErr, int sqrtScore,
+						 int* pairs, double* fit, void* colTop, DevBuf& work) {
+	return phase1<double>(ctx, false, src, nsLocal, srcBegin, dst, nd, dof, maxErr, sqrtScore, pairs, fit, (ColTop*)colTop, work);
+}
+int bhip_assoc_phase1_ham(bhip_ctx* ctx, const int32_t* src, int nsLocal, int srcBegin, const int32_t* dst, int nd, int words, double maxErr, int* pairs,
+						  double* fit, void* colTop, DevBuf& work) {
+	return phase1<int>(ctx, true, (const int*)src, nsLocal, srcBegin, (const int*)dst, nd, words, maxErr, 0, pairs, fit, (ColTop*)colTop, work);
+}
+int bhip_assoc_phase2(bhip_ctx* ctx, const void* colAll, int nranks, int nd, int nsLocal, int srcBegin, int* pairs, double* fit) {
+	return phase2(ctx, (const ColTop*)colAll, nranks, nd, nsLocal, srcBegin, pairs, fit);
+}
+int bhip_assoc_coltop_size() { return (int)sizeof(ColTop); }

@@ -1,0 +1,788 @@
+// C ABI of libboofhip.so (include/boofhip.h): context, the SURF detect+describe object, association, stage-level entry points.
+// Host orchestration only -- all arithmetic lives in the kernels.  There is deliberately no CPU fallback.
+#include "common.h"
+#include <cmath>
+#include <cfloat>
+#include <algorithm>
+#include <memory>
+
+// launchers defined in the other translation units
+int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int cap, const int* imageStart, int batch, int singleImage, long long total,
+							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white);
+int bhip_assoc_phase1_l2(bhip_ctx* ctx, const double* src, int nsLocal, int srcBegin, const double* dst, int nd, int dof, double maxErr, int sqrtScore,
+						 int* pairs, double* fit, void* colTop, DevBuf& work);
+int bhip_assoc_phase1_ham(bhip_ctx* ctx, const int32_t* src, int nsLocal, int srcBegin, const int32_t* dst, int nd, int words, double maxErr, int* pairs,
+						  double* fit, void* colTop, DevBuf& work);
+int bhip_assoc_phase2(bhip_ctx* ctx, const void* colAll, int nranks, int nd, int nsLocal, int srcBegin, int* pairs, double* fit);
+int bhip_assoc_coltop_size();
+int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
+					 int height, float* out, int outStride);
+int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
+int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
+					  const int* compare, const double* xy, int n, int* out);
+
+// per-context scratch that the stateless entry points reuse
+struct CtxScratch {
+	DevBuf a, b, c, d, e, work;
+};
+static CtxScratch* scratchOf(bhip_ctx* ctx);
+
+struct bhip_ctx_full : bhip_ctx {
+	CtxScratch scratch;
+};
+static CtxScratch* scratchOf(bhip_ctx* ctx) { return &static_cast<bhip_ctx_full*>(ctx)->scratch; }
+
+extern "C" {
+
+const char* bhip_version(void) { return "boofhip 0.1 (gfx950)"; }
+
+void bhip_fh_cfg_default(bhip_fh_cfg* c) {
+	c->detectThreshold = 1; c->extractRadius = 2; c->maxFeaturesPerScale = -1; c->initialSampleSize = 1; c->initialSize = 9;
+	c->numberScalesPerOctave = 4; c->numberOfOctaves = 4; c->scaleStepSize = 6;
+}
+void bhip_surf_cfg_default(bhip_surf_cfg* c) {
+	c->widthLargeGrid = 4; c->widthSubRegion = 5; c->widthSample = 3; c->weightSigma = 4.5; c->overLap = 2; c->sigmaLargeGrid = 2.5;
+	c->sigmaSubRegion = 2.5;
+}
+void bhip_ori_cfg_default(bhip_ori_cfg* c, int stable) {
+	c->objectRadiusToScale = 1.0 / 2.0;
+	c->weightSigma = -1;
+	c->sampleWidth = 6;
+	if (stable) { c->samplePeriod = 0.65; c->windowSize = M_PI / 3.0; c->radius = 8; }
+	else { c->samplePeriod = 1; c->windowSize = 0; c->radius = 6; }
+}
+
+static int ctxCreate(int device, void* stream, bool useGiven, bhip_ctx** out) {
+	if (!out) return BHIP_ERR_INVALID;
+	*out = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return BHIP_ERR_HIP;  // no GPU: fail loudly, never fall back
+	if (device < 0 || device >= count) return BHIP_ERR_INVALID;
+	if (hipSetDevice(device) != hipSuccess) return BHIP_ERR_HIP;
+	bhip_ctx_full* ctx = new (std::nothrow) bhip_ctx_full();
+	if (!ctx) return BHIP_ERR_NOMEM;
+	ctx->device = device;
+	if (useGiven) {
+		ctx->stream = (hipStream_t)stream;
+		ctx->ownStream = false;
+	} else {
+		if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BHIP_ERR_HIP; }
+		ctx->ownStream = true;
+	}
+	if (hipHostMalloc((void**)&ctx->hostScratch, 1 << 20, hipHostMallocDefault) != hipSuccess) {
+		if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
+		delete ctx;
+		return BHIP_ERR_HIP;
+	}
+	*out = ctx;
+	return BHIP_OK;
+}
+int bhip_ctx_create(int device, bhip_ctx** out) { return ctxCreate(device, nullptr, false, out); }
+int bhip_ctx_create_on_stream(int device, void* hip_stream, bhip_ctx** out) { return ctxCreate(device, hip_stream, true, out); }
+int bhip_ctx_destroy(bhip_ctx* c) {
+	if (!c) return BHIP_OK;
+	bhip_ctx_full* ctx = static_cast<bhip_ctx_full*>(c);
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	CtxScratch& s = ctx->scratch;
+	s.a.release(); s.b.release(); s.c.release(); s.d.release(); s.e.release(); s.work.release();
+	if (ctx->hostScratch) (void)hipHostFree(ctx->hostScratch);
+	if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return BHIP_OK;
+}
+int bhip_ctx_synchronize(bhip_ctx* ctx) {
+	if (!ctx) return BHIP_ERR_INVALID;
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+const char* bhip_last_error(bhip_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+}  // extern "C"
+
+#define CHECK_CTX(ctx)                                   \
+	do {                                                 \
+		if (!(ctx)) return BHIP_ERR_INVALID;             \
+		BHIP_HIP((ctx), hipSetDevice((ctx)->device));    \
+	} while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast-Hessian detector: octave schedule + buffers (FastHessianFeatureDetector.detect :156-188, detectOctave :198-221)
+// ---------------------------------------------------------------------------------------------------------------
+struct FhLevelPlan {
+	DetectLevelParams p;
+	int level;  // index of the mid level inside its octave
+};
+struct FhOctavePlan {
+	int skip, w, h, nlevels;
+	int sizes[BHIP_MAX_LEVELS];
+	std::vector<FhLevelPlan> mids;
+};
+
+struct FhDetector {
+	bhip_fh_cfg cfg;
+	int W = 0, H = 0, batch = 0, cap = 0;
+	std::vector<FhOctavePlan> plan;
+	int bitmapWords = 0;
+	DevBuf inten, bitmap, prefix, cand, sorted, count;
+	std::vector<int> counts;   // per image, host
+	long long total = 0;
+
+	int makePlan(bhip_ctx* ctx, int width, int height) {
+		plan.clear();
+		if (cfg.numberScalesPerOctave > BHIP_MAX_LEVELS || cfg.numberScalesPerOctave < 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "numberScalesPerOctave out of range");
+		if (cfg.maxFeaturesPerScale > 0) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "maxFeaturesPerScale > 0 (QuickSelect order unpinned): use the Java path");
+		if (cfg.extractRadius < 1) return bhip_fail(ctx, BHIP_ERR_INVALID, "Search radius must be >= 1");
+		if (cfg.initialSampleSize < 1 || cfg.initialSize < 3) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sample size / initial size");
+		if (width >= 32768 || height >= 32768) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "image too large for Point2D_I16");
+		int skip = cfg.initialSampleSize, sizeStep = cfg.scaleStepSize, octaveSize = cfg.initialSize;
+		unsigned int bits = 0;
+		const int step = cfg.extractRadius + 1;
+		for (int octave = 0; octave < cfg.numberOfOctaves; octave++) {
+			FhOctavePlan o;
+			o.nlevels = cfg.numberScalesPerOctave;
+			for (int i = 0; i < o.nlevels; i++) o.sizes[i] = octaveSize + i * sizeStep;
+			const int maxSize = o.sizes[o.nlevels - 1];
+			if (maxSize > width || maxSize > height) break;
+			o.skip = skip;
+			o.w = width / skip;
+			o.h = height / skip;
+			for (int i = 2; i < o.nlevels; i++) {
+				FhLevelPlan m;
+				m.level = i - 1;
+				DetectLevelParams& p = m.p;
+				p.skip = skip; p.w = o.w; p.h = o.h;
+				p.sizeLower = o.sizes[m.level - 1]; p.sizeMid = o.sizes[m.level]; p.sizeUpper = o.sizes[m.level + 1];
+				p.border = p.sizeMid / (2 * skip);
+				const int rw = p.w - 2 * p.border, rh = p.h - 2 * p.border;
+				p.nbx = rw > 0 ? (rw + step - 1) / step : 0;
+				p.nby = rh > 0 ? (rh + step - 1) / step : 0;
+				p.bitBase = bits;
+				bits += (unsigned)p.nbx * (unsigned)p.nby;
+				o.mids.push_back(m);
+			}
+			plan.push_back(o);
+			skip += skip;
+			octaveSize += sizeStep;
+			sizeStep += sizeStep;
+		}
+		bitmapWords = (int)((bits + 31) / 32) + 1;
+		return BHIP_OK;
+	}
+
+	int prepare(bhip_ctx* ctx, int width, int height, int batch_) {
+		if (width != W || height != H) BHIP_TRY(makePlan(ctx, width, height));
+		W = width; H = height; batch = batch_;
+		if (cap == 0) cap = 8192;
+		return allocate(ctx);
+	}
+	int allocate(bhip_ctx* ctx) {
+		size_t intenBytes = 0;
+		for (auto& o : plan) intenBytes = std::max(intenBytes, (size_t)o.nlevels * o.w * o.h * sizeof(float));
+		BHIP_TRY(inten.reserve(ctx, intenBytes * batch + 16));
+		BHIP_TRY(bitmap.reserve(ctx, (size_t)bitmapWords * 4 * batch));
+		BHIP_TRY(prefix.reserve(ctx, (size_t)bitmapWords * 4 * batch));
+		BHIP_TRY(cand.reserve(ctx, (size_t)cap * sizeof(KeyPoint) * batch));
+		BHIP_TRY(sorted.reserve(ctx, (size_t)cap * sizeof(KeyPoint) * batch));
+		BHIP_TRY(count.reserve(ctx, (size_t)batch * 4 * 2));
+		return BHIP_OK;
+	}
+
+	// ii: dense integral images.  Leaves the ordered key points in `sorted` ([image][cap]) and their counts in `counts`.
+	int run(bhip_ctx* ctx, ImgView ii) {
+		for (int attempt = 0; attempt < 8; attempt++) {
+			BHIP_HIP(ctx, hipMemsetAsync(bitmap.p, 0, (size_t)bitmapWords * 4 * batch, ctx->stream));
+			BHIP_HIP(ctx, hipMemsetAsync(count.p, 0, (size_t)batch * 4 * 2, ctx->stream));
+			for (auto& o : plan) {
+				const long long levelStride = (long long)o.w * o.h;
+				const long long imageStride = levelStride * o.nlevels;
+				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, inten.as<float>(), levelStride, imageStride, o.w));
+				for (auto& m : o.mids) {
+					const float* base = inten.as<float>();
+					BHIP_TRY(bhip_launch_nms_scalespace(ctx, base + (m.level - 1) * levelStride, base + m.level * levelStride, base + (m.level + 1) * levelStride,
+														imageStride, o.w, batch, m.p, cfg.extractRadius, cfg.detectThreshold, bitmap.as<unsigned int>(),
+														bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap));
+				}
+			}
+			BHIP_TRY(bhip_launch_word_prefix(ctx, bitmap.as<unsigned int>(), bitmapWords, batch, prefix.as<unsigned int>(), count.as<int>() + batch));
+			counts.resize(batch);
+			if ((size_t)batch * 4 <= (1u << 20)) {
+				BHIP_HIP(ctx, hipMemcpyAsync(ctx->hostScratch, count.p, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+				BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+				memcpy(counts.data(), ctx->hostScratch, (size_t)batch * 4);
+			} else {
+				BHIP_HIP(ctx, hipMemcpyAsync(counts.data(), count.p, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+				BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			}
+			int maxCount = 0;
+			total = 0;
+			for (int c : counts) { maxCount = std::max(maxCount, c); total += c; }
+			if (maxCount <= cap) {
+				BHIP_TRY(bhip_launch_rank_scatter(ctx, bitmap.as<unsigned int>(), bitmapWords, prefix.as<unsigned int>(), cand.as<KeyPoint>(), count.as<int>(),
+												  cap, batch, sorted.as<KeyPoint>()));
+				return BHIP_OK;
+			}
+			// candidate list overflowed: grow and run the detector again
+			cap = maxCount + maxCount / 4 + 64;
+			BHIP_TRY(allocate(ctx));
+		}
+		return bhip_fail(ctx, BHIP_ERR_CAPACITY, "key point list kept overflowing");
+	}
+	void release() { inten.release(); bitmap.release(); prefix.release(); cand.release(); sorted.release(); count.release(); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// SURF detect + describe object
+// ---------------------------------------------------------------------------------------------------------------
+struct bhip_surf {
+	bhip_ctx* ctx = nullptr;
+	int stable = 1;
+	bhip_surf_cfg sd;
+	bhip_ori_cfg ori;
+	FhDetector det;
+	SurfTables tables;
+	DevBuf tabBuf, inBuf, iiBuf, startBuf, angBuf, descBuf, whiteBuf, xysBuf, tmpKp, tmpAng, tmpDesc, tmpWhite;
+	std::vector<int> starts;  // batch+1
+	int W = 0, H = 0, batch = 0;
+	bool haveResult = false;
+	ImgView iiView;
+};
+
+static int buildTables(bhip_surf* s) {
+	bhip_ctx* ctx = s->ctx;
+	SurfTables& t = s->tables;
+	memset(&t, 0, sizeof(t));
+	const bhip_surf_cfg& c = s->sd;
+	const bhip_ori_cfg& o = s->ori;
+	if (c.widthLargeGrid < 1 || c.widthSubRegion < 1 || c.widthSample < 1 || c.overLap < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad SURF config");
+	if (o.radius < 1 || o.radius > 16) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation radius out of range");
+	std::vector<double> all;
+	auto push = [&](const std::vector<double>& v) { size_t off = all.size(); all.insert(all.end(), v.begin(), v.end()); return off; };
+	t.oriStable = s->stable;
+	t.oriRadius = o.radius;
+	t.oriWidth = 2 * o.radius + 1;
+	t.oriKernelWidth = o.sampleWidth;
+	t.oriHasWeights = o.weightSigma != 0 ? 1 : 0;
+	t.oriPeriod = o.samplePeriod;
+	t.oriWindow = o.windowSize;
+	t.oriRadiusToScale = o.objectRadiusToScale;
+	size_t offOri = 0, offSub = 0, offGrid = 0, offFast = 0;
+	// OrientationIntegralBase :85-86 weights = FactoryKernelGaussian.gaussian(2,true,64,weightSigma,sampleRadius)
+	if (t.oriHasWeights) offOri = push(bhip_gaussian2d_f64(o.weightSigma, o.radius));
+	t.stable = s->stable;
+	t.widthLargeGrid = c.widthLargeGrid; t.widthSubRegion = c.widthSubRegion; t.widthSample = c.widthSample; t.overLap = c.overLap;
+	t.dof = c.widthLargeGrid * c.widthLargeGrid * 4;
+	const int regionSize = c.widthLargeGrid * c.widthSubRegion;
+	if (s->stable) {
+		// DescribePointSurfMod :76-106
+		std::vector<double> wg = bhip_gaussian_width(c.sigmaLargeGrid, c.widthLargeGrid);
+		std::vector<double> ws = bhip_gaussian_width(c.sigmaSubRegion, c.widthSubRegion + 2 * c.overLap);
+		const int gw = c.widthLargeGrid, sw = c.widthSubRegion + 2 * c.overLap;
+		double div = wg[(size_t)(gw / 2) * gw + gw / 2];
+		for (double& v : wg) v /= div;
+		div = ws[(size_t)(sw / 2) * sw + sw / 2];
+		for (double& v : ws) v /= div;
+		offGrid = push(wg);
+		offSub = push(ws);
+		t.radiusDescriptor = regionSize / 2 + c.overLap;
+	} else {
+		// DescribePointSurf :110-141
+		const int radius = regionSize / 2;
+		std::vector<double> w = bhip_gaussian_width(c.weightSigma, radius * 2);
+		if ((int)w.size() != regionSize * regionSize) return bhip_fail(ctx, BHIP_ERR_INVALID, "Weighting kernel has an unexpected size");
+		const double div = w[(size_t)radius * (radius * 2) + radius];
+		for (double& v : w) v /= div;
+		offFast = push(w);
+		t.radiusDescriptor = regionSize / 2;
+	}
+	BHIP_TRY(s->tabBuf.reserve(ctx, all.size() * 8 + 8));
+	BHIP_HIP(ctx, hipMemcpyAsync(s->tabBuf.p, all.data(), all.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const double* base = s->tabBuf.as<double>();
+	t.oriWeights = t.oriHasWeights ? base + offOri : nullptr;
+	t.weightSub = s->stable ? base + offSub : nullptr;
+	t.weightGrid = s->stable ? base + offGrid : nullptr;
+	t.weightFast = s->stable ? nullptr : base + offFast;
+	return BHIP_OK;
+}
+
+static int surfRun(bhip_surf* s, ImgView in, int batch) {
+	bhip_ctx* ctx = s->ctx;
+	const int W = in.width, H = in.height;
+	s->haveResult = false;
+	BHIP_TRY(s->det.prepare(ctx, W, H, batch));
+	BHIP_TRY(s->iiBuf.reserve(ctx, (size_t)W * H * 4 * batch));
+	s->W = W; s->H = H; s->batch = batch;
+	ImgViewW iiW{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
+	BHIP_TRY(bhip_launch_integral(ctx, in, iiW, batch));
+	ImgView ii{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
+	s->iiView = ii;
+	BHIP_TRY(s->det.run(ctx, ii));
+	// exclusive prefix of counts -> start of every image in the compact result arrays
+	s->starts.assign(batch + 1, 0);
+	for (int i = 0; i < batch; i++) s->starts[i + 1] = s->starts[i] + s->det.counts[i];
+	const long long total = s->det.total;
+	if (total > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_CAPACITY, "more than 2^31 key points in one batch");
+	BHIP_TRY(s->startBuf.reserve(ctx, (size_t)(batch + 1) * 4));
+	BHIP_HIP(ctx, hipMemcpyAsync(s->startBuf.p, s->starts.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	const int dof = s->tables.dof;
+	BHIP_TRY(s->angBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8));
+	BHIP_TRY(s->descBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8 * dof));
+	BHIP_TRY(s->whiteBuf.reserve(ctx, (size_t)std::max<long long>(total, 1)));
+	BHIP_TRY(bhip_launch_describe_ex(ctx, ii, s->det.sorted.as<KeyPoint>(), s->det.cap, s->startBuf.as<int>(), batch, 0, total, s->tables, nullptr,
+									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>()));
+	// the host vector `starts` was handed to an async copy: make sure it is consumed before it can change
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	s->haveResult = true;
+	return BHIP_OK;
+}
+
+extern "C" {
+
+int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out) {
+	CHECK_CTX(ctx);
+	if (!out) return bhip_fail(ctx, BHIP_ERR_INVALID, "null output");
+	*out = nullptr;
+	std::unique_ptr<bhip_surf> s(new (std::nothrow) bhip_surf());
+	if (!s) return bhip_fail(ctx, BHIP_ERR_NOMEM, "out of host memory");
+	s->ctx = ctx;
+	s->stable = stable ? 1 : 0;
+	if (fh) s->det.cfg = *fh; else bhip_fh_cfg_default(&s->det.cfg);
+	if (surf) s->sd = *surf; else bhip_surf_cfg_default(&s->sd);
+	if (ori) s->ori = *ori; else bhip_ori_cfg_default(&s->ori, s->stable);
+	BHIP_TRY(buildTables(s.get()));
+	*out = s.release();
+	return BHIP_OK;
+}
+
+int bhip_surf_destroy(bhip_surf* s) {
+	if (!s) return BHIP_OK;
+	(void)hipSetDevice(s->ctx->device);
+	(void)hipStreamSynchronize(s->ctx->stream);
+	s->det.release();
+	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite};
+	for (DevBuf* b : bufs) b->release();
+	delete s;
+	return BHIP_OK;
+}
+
+int bhip_surf_dof(bhip_surf* s) { return s ? s->tables.dof : 0; }
+
+int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long imageStride, int stride, int width, int height, int batch) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!dev_images || width <= 0 || height <= 0 || batch <= 0 || stride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image batch");
+	ImgView in{dev_images, imageStride, stride, width, height};
+	return surfRun(s, in, batch);
+}
+
+int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* startIndex, const int* stride, int width, int height, int batch) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!img || width <= 0 || height <= 0 || batch <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image batch");
+	const size_t imgBytes = (size_t)width * height * 4;
+	BHIP_TRY(s->inBuf.reserve(ctx, imgBytes * batch));
+	for (int i = 0; i < batch; i++) {
+		const int st = stride ? stride[i] : width;
+		if (!img[i] || st < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
+		const float* src = img[i] + (startIndex ? startIndex[i] : 0);
+		BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width * 4, src, (size_t)st * 4, (size_t)width * 4, height,
+									   hipMemcpyHostToDevice, ctx->stream));
+	}
+	ImgView in{s->inBuf.as<float>(), (long long)width * height, width, width, height};
+	return surfRun(s, in, batch);
+}
+
+int bhip_surf_count(bhip_surf* s, int image, int* n) {
+	if (!s || !n) return BHIP_ERR_INVALID;
+	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	*n = s->det.counts[image];
+	return BHIP_OK;
+}
+int bhip_surf_total(bhip_surf* s, long long* n) {
+	if (!s || !n) return BHIP_ERR_INVALID;
+	*n = s->haveResult ? s->det.total : 0;
+	return BHIP_OK;
+}
+
+int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, uint8_t* white, double* desc) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	const int n = s->det.counts[image];
+	if (n == 0) return BHIP_OK;
+	const long long off = s->starts[image];
+	const int dof = s->tables.dof;
+	std::vector<KeyPoint> kps;
+	if (xy_scale) {
+		kps.resize(n);
+		BHIP_HIP(ctx, hipMemcpyAsync(kps.data(), s->det.sorted.as<KeyPoint>() + (long long)image * s->det.cap, (size_t)n * sizeof(KeyPoint),
+									 hipMemcpyDeviceToHost, ctx->stream));
+	}
+	if (angle) BHIP_HIP(ctx, hipMemcpyAsync(angle, s->angBuf.as<double>() + off, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+	if (white) BHIP_HIP(ctx, hipMemcpyAsync(white, s->whiteBuf.as<uint8_t>() + off, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+	if (desc) BHIP_HIP(ctx, hipMemcpyAsync(desc, s->descBuf.as<double>() + off * dof, (size_t)n * 8 * dof, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (xy_scale)
+		for (int i = 0; i < n; i++) { xy_scale[3 * i] = kps[i].x; xy_scale[3 * i + 1] = kps[i].y; xy_scale[3 * i + 2] = kps[i].scale; }
+	return BHIP_OK;
+}
+
+int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const double** dev_xy_scale, const uint8_t** dev_white, int* n) {
+	if (!s) return BHIP_ERR_INVALID;
+	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	const long long off = s->starts[image];
+	if (dev_desc) *dev_desc = s->descBuf.as<double>() + off * s->tables.dof;
+	// key points are KeyPoint records {x,y,scale,key,pad}: 32-byte stride, first three doubles are x,y,scale
+	if (dev_xy_scale) *dev_xy_scale = (const double*)(s->det.sorted.as<KeyPoint>() + (long long)image * s->det.cap);
+	if (dev_white) *dev_white = s->whiteBuf.as<uint8_t>() + off;
+	if (n) *n = s->det.counts[image];
+	return BHIP_OK;
+}
+
+int bhip_surf_fetch_integral(bhip_surf* s, int image, float* out) {
+	if (!s || !out) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	BHIP_HIP(ctx, hipMemcpyAsync(out, s->iiBuf.as<float>() + (long long)image * s->W * s->H, (size_t)s->W * s->H * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
+int bhip_surf_describe_points(bhip_surf* s, int image, const double* xy_scale, int n, double* angle, uint8_t* white, double* desc) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	if (n < 0 || (n > 0 && !xy_scale)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad point list");
+	if (n == 0) return BHIP_OK;
+	std::vector<KeyPoint> kps(n);
+	for (int i = 0; i < n; i++) { kps[i].x = xy_scale[3 * i]; kps[i].y = xy_scale[3 * i + 1]; kps[i].scale = xy_scale[3 * i + 2]; kps[i].key = 0; kps[i].pad = 0; }
+	const int dof = s->tables.dof;
+	BHIP_TRY(s->tmpKp.reserve(ctx, (size_t)n * sizeof(KeyPoint)));
+	BHIP_TRY(s->tmpAng.reserve(ctx, (size_t)n * 8));
+	BHIP_TRY(s->tmpDesc.reserve(ctx, (size_t)n * 8 * dof));
+	BHIP_TRY(s->tmpWhite.reserve(ctx, (size_t)n));
+	BHIP_HIP(ctx, hipMemcpyAsync(s->tmpKp.p, kps.data(), (size_t)n * sizeof(KeyPoint), hipMemcpyHostToDevice, ctx->stream));
+	BHIP_TRY(bhip_launch_describe_ex(ctx, s->iiView, s->tmpKp.as<KeyPoint>(), 0, nullptr, s->batch, image, n, s->tables, nullptr, s->tmpAng.as<double>(),
+									 s->tmpDesc.as<double>(), s->tmpWhite.as<uint8_t>()));
+	if (angle) BHIP_HIP(ctx, hipMemcpyAsync(angle, s->tmpAng.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+	if (white) BHIP_HIP(ctx, hipMemcpyAsync(white, s->tmpWhite.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+	if (desc) BHIP_HIP(ctx, hipMemcpyAsync(desc, s->tmpDesc.p, (size_t)n * 8 * dof, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage-level entry points (host buffers in / out)
+// ---------------------------------------------------------------------------------------------------------------
+static int uploadImage(bhip_ctx* ctx, DevBuf& buf, const float* in, int start, int stride, int w, int h) {
+	BHIP_TRY(buf.reserve(ctx, (size_t)w * h * 4));
+	BHIP_HIP(ctx, hipMemcpy2DAsync(buf.p, (size_t)w * 4, in + start, (size_t)stride * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
+	return BHIP_OK;
+}
+static int downloadImage(bhip_ctx* ctx, const void* dev, float* out, int start, int stride, int w, int h) {
+	BHIP_HIP(ctx, hipMemcpy2DAsync(out + start, (size_t)stride * 4, dev, (size_t)w * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+#define CHECK_IMG(ctx, p, stride, w, h)                                                                                 \
+	do {                                                                                                                \
+		if (!(p) || (w) <= 0 || (h) <= 0 || (stride) < (w)) return bhip_fail((ctx), BHIP_ERR_INVALID, "bad image");     \
+	} while (0)
+
+int bhip_integral_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* out, int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, width, height);
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
+	ImgView iv{sc->a.as<float>(), (long long)width * height, width, width, height};
+	ImgViewW ov{sc->b.as<float>(), (long long)width * height, width, width, height};
+	BHIP_TRY(bhip_launch_integral(ctx, iv, ov, 1));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, width, height);
+}
+
+int bhip_hessian_f32(bhip_ctx* ctx, const float* ii, int iiStart, int iiStride, int width, int height, int skip, int size, float* intensity,
+					 int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, ii, iiStride, width, height);
+	if (skip < 1 || size < 3) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad skip/size");
+	const int w = width / skip, h = height / skip;
+	if (w <= 0 || h <= 0) return BHIP_OK;
+	CHECK_IMG(ctx, intensity, outStride, w, h);
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, ii, iiStart, iiStride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)w * h * 4));
+	ImgView iv{sc->a.as<float>(), (long long)width * height, width, width, height};
+	BHIP_TRY(bhip_launch_hessian(ctx, iv, 1, skip, 1, &size, sc->b.as<float>(), (long long)w * h, (long long)w * h, w));
+	return downloadImage(ctx, sc->b.p, intensity, outStart, outStride, w, h);
+}
+
+int bhip_nonmax_block_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, int radius, float threshold,
+						  int border, int16_t* xy, int cap, int* n) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, intensity, stride, width, height);
+	if (!n || cap < 0 || (cap > 0 && !xy)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad output");
+	if (radius < 1) return bhip_fail(ctx, BHIP_ERR_INVALID, "Search radius must be >= 1");
+	if (border < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Ignore border must be >= 0 ");
+	if (width >= 32768 || height >= 32768) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "image too large for Point2D_I16");
+	*n = 0;
+	const int step = radius + 1;
+	const int rw = width - 2 * border, rh = height - 2 * border;
+	if (rw <= 0 || rh <= 0) return BHIP_OK;
+	const int nbx = (rw + step - 1) / step, nby = (rh + step - 1) / step;
+	const int words = (int)(((long long)nbx * nby + 31) / 32) + 1;
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, intensity, start, stride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)words * 4));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)words * 4));
+	BHIP_TRY(sc->d.reserve(ctx, 16));
+	BHIP_TRY(sc->e.reserve(ctx, (size_t)std::max(cap, 1) * 4));
+	BHIP_HIP(ctx, hipMemsetAsync(sc->b.p, 0, (size_t)words * 4, ctx->stream));
+	BHIP_TRY(bhip_launch_nonmax_only(ctx, sc->a.as<float>(), width, width, height, radius, threshold, border, sc->b.as<unsigned int>(), words, nbx, nby));
+	BHIP_TRY(bhip_launch_word_prefix(ctx, sc->b.as<unsigned int>(), words, 1, sc->c.as<unsigned int>(), sc->d.as<int>()));
+	BHIP_TRY(bhip_launch_bitmap_to_xy(ctx, sc->a.as<float>(), width, width, height, radius, threshold, border, sc->b.as<unsigned int>(),
+									  sc->c.as<unsigned int>(), words, nbx, nby, sc->e.as<int16_t>(), cap));
+	BHIP_HIP(ctx, hipMemcpyAsync(ctx->hostScratch, sc->d.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*n = ctx->hostScratch[0];
+	const int ncopy = std::min(*n, cap);
+	if (ncopy > 0) {
+		BHIP_HIP(ctx, hipMemcpyAsync(xy, sc->e.p, (size_t)ncopy * 4, hipMemcpyDeviceToHost, ctx->stream));
+		BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return BHIP_OK;
+}
+
+int bhip_fh_detect_f32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const float* ii, int iiStart, int iiStride, int width, int height, double* xy_scale,
+					   int cap, int* n) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, ii, iiStride, width, height);
+	if (!n || cap < 0 || (cap > 0 && !xy_scale)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad output");
+	*n = 0;
+	FhDetector det;
+	if (cfg) det.cfg = *cfg; else bhip_fh_cfg_default(&det.cfg);
+	CtxScratch* sc = scratchOf(ctx);
+	int status = uploadImage(ctx, sc->a, ii, iiStart, iiStride, width, height);
+	if (status == BHIP_OK) status = det.prepare(ctx, width, height, 1);
+	ImgView iv{sc->a.as<float>(), (long long)width * height, width, width, height};
+	if (status == BHIP_OK) status = det.run(ctx, iv);
+	if (status == BHIP_OK) {
+		*n = det.counts[0];
+		const int ncopy = std::min(*n, cap);
+		if (ncopy > 0) {
+			std::vector<KeyPoint> kps(ncopy);
+			hipError_t e = hipMemcpyAsync(kps.data(), det.sorted.p, (size_t)ncopy * sizeof(KeyPoint), hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			if (e != hipSuccess) status = bhip_fail(ctx, BHIP_ERR_HIP, hipGetErrorString(e));
+			else for (int i = 0; i < ncopy; i++) { xy_scale[3 * i] = kps[i].x; xy_scale[3 * i + 1] = kps[i].y; xy_scale[3 * i + 2] = kps[i].scale; }
+		}
+	}
+	(void)hipStreamSynchronize(ctx->stream);
+	det.release();
+	return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// association
+// ---------------------------------------------------------------------------------------------------------------
+int bhip_assoc_coltop_bytes(void) { return bhip_assoc_coltop_size(); }
+
+int bhip_assoc_l2_dev(bhip_ctx* ctx, const double* dev_src, int ns, const double* dev_dst, int nd, int dof, double maxErr, int backwards,
+					  int sqrtScore, int* dev_pairs, double* dev_fit) {
+	CHECK_CTX(ctx);
+	if (ns < 0 || nd < 0 || dof <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+	if (ns == 0) return BHIP_OK;
+	CtxScratch* sc = scratchOf(ctx);
+	void* col = nullptr;
+	if (backwards && nd > 0) { BHIP_TRY(sc->d.reserve(ctx, (size_t)nd * bhip_assoc_coltop_size())); col = sc->d.p; }
+	BHIP_TRY(bhip_assoc_phase1_l2(ctx, dev_src, ns, 0, dev_dst, nd, dof, maxErr, sqrtScore, dev_pairs, dev_fit, col, sc->work));
+	if (col) BHIP_TRY(bhip_assoc_phase2(ctx, col, 1, nd, ns, 0, dev_pairs, dev_fit));
+	return BHIP_OK;
+}
+int bhip_assoc_hamming_dev(bhip_ctx* ctx, const int32_t* dev_src, int ns, const int32_t* dev_dst, int nd, int words, double maxErr, int backwards,
+						   int* dev_pairs, double* dev_fit) {
+	CHECK_CTX(ctx);
+	if (ns < 0 || nd < 0 || words <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+	if (ns == 0) return BHIP_OK;
+	CtxScratch* sc = scratchOf(ctx);
+	void* col = nullptr;
+	if (backwards && nd > 0) { BHIP_TRY(sc->d.reserve(ctx, (size_t)nd * bhip_assoc_coltop_size())); col = sc->d.p; }
+	BHIP_TRY(bhip_assoc_phase1_ham(ctx, dev_src, ns, 0, dev_dst, nd, words, maxErr, dev_pairs, dev_fit, col, sc->work));
+	if (col) BHIP_TRY(bhip_assoc_phase2(ctx, col, 1, nd, ns, 0, dev_pairs, dev_fit));
+	return BHIP_OK;
+}
+
+int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double* dev_dst, int dof, int count, const long long* srcOff, const int* ns,
+							  const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit) {
+	CHECK_CTX(ctx);
+	if (count < 0 || dof <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+	for (int p = 0; p < count; p++) {
+		BHIP_TRY(bhip_assoc_l2_dev(ctx, dev_src + srcOff[p] * dof, ns[p], dev_dst + dstOff[p] * dof, nd[p], dof, maxErr, backwards, 0, dev_pairs + srcOff[p],
+								   dev_fit + srcOff[p]));
+	}
+	return BHIP_OK;
+}
+
+}  // extern "C"
+
+template <class E>
+static int assocHost(bhip_ctx* ctx, bool hamming, const E* src, int ns, const E* dst, int nd, int len, double maxErr, int backwards, int sqrtScore,
+					 int* pairs, double* fit) {
+	if (ns < 0 || nd < 0 || len <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+	if (ns == 0) return BHIP_OK;
+	if (!src || (nd > 0 && !dst) || !pairs || !fit) return bhip_fail(ctx, BHIP_ERR_INVALID, "null buffer");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(sc->a.reserve(ctx, (size_t)ns * len * sizeof(E)));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)std::max(nd, 1) * len * sizeof(E)));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)ns * 4));
+	BHIP_TRY(sc->e.reserve(ctx, (size_t)ns * 8));
+	BHIP_HIP(ctx, hipMemcpyAsync(sc->a.p, src, (size_t)ns * len * sizeof(E), hipMemcpyHostToDevice, ctx->stream));
+	if (nd > 0) BHIP_HIP(ctx, hipMemcpyAsync(sc->b.p, dst, (size_t)nd * len * sizeof(E), hipMemcpyHostToDevice, ctx->stream));
+	if (hamming) BHIP_TRY(bhip_assoc_hamming_dev(ctx, (const int32_t*)sc->a.p, ns, (const int32_t*)sc->b.p, nd, len, maxErr, backwards, sc->c.as<int>(), sc->e.as<double>()));
+	else BHIP_TRY(bhip_assoc_l2_dev(ctx, (const double*)sc->a.p, ns, (const double*)sc->b.p, nd, len, maxErr, backwards, sqrtScore, sc->c.as<int>(), sc->e.as<double>()));
+	BHIP_HIP(ctx, hipMemcpyAsync(pairs, sc->c.p, (size_t)ns * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(fit, sc->e.p, (size_t)ns * 8, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
+extern "C" {
+
+int bhip_assoc_l2_f64(bhip_ctx* ctx, const double* src, int ns, const double* dst, int nd, int dof, double maxErr, int backwards, int sqrtScore,
+					  int* pairs, double* fit) {
+	CHECK_CTX(ctx);
+	return assocHost<double>(ctx, false, src, ns, dst, nd, dof, maxErr, backwards, sqrtScore, pairs, fit);
+}
+int bhip_assoc_hamming(bhip_ctx* ctx, const int32_t* src, int ns, const int32_t* dst, int nd, int words, double maxErr, int backwards, int* pairs,
+					   double* fit) {
+	CHECK_CTX(ctx);
+	return assocHost<int32_t>(ctx, true, src, ns, dst, nd, words, maxErr, backwards, 0, pairs, fit);
+}
+
+int bhip_assoc_l2_shard_phase1(bhip_ctx* ctx, const double* dev_src, int nsLocal, int srcBegin, const double* dev_dst, int nd, int dof, double maxErr,
+							   int* dev_pairs, double* dev_fit, void* dev_colTop) {
+	CHECK_CTX(ctx);
+	if (!dev_colTop) return bhip_fail(ctx, BHIP_ERR_INVALID, "null column buffer");
+	return bhip_assoc_phase1_l2(ctx, dev_src, nsLocal, srcBegin, dev_dst, nd, dof, maxErr, 0, dev_pairs, dev_fit, dev_colTop, scratchOf(ctx)->work);
+}
+int bhip_assoc_hamming_shard_phase1(bhip_ctx* ctx, const int32_t* dev_src, int nsLocal, int srcBegin, const int32_t* dev_dst, int nd, int words,
+									double maxErr, int* dev_pairs, double* dev_fit, void* dev_colTop) {
+	CHECK_CTX(ctx);
+	if (!dev_colTop) return bhip_fail(ctx, BHIP_ERR_INVALID, "null column buffer");
+	return bhip_assoc_phase1_ham(ctx, dev_src, nsLocal, srcBegin, dev_dst, nd, words, maxErr, dev_pairs, dev_fit, dev_colTop, scratchOf(ctx)->work);
+}
+int bhip_assoc_shard_phase2(bhip_ctx* ctx, const void* dev_colTopAll, int nranks, int nd, int nsLocal, int srcBegin, int* dev_pairs, double* dev_fit) {
+	CHECK_CTX(ctx);
+	if (nranks < 1) return bhip_fail(ctx, BHIP_ERR_INVALID, "nranks < 1");
+	return bhip_assoc_phase2(ctx, dev_colTopAll, nranks, nd, nsLocal, srcBegin, dev_pairs, dev_fit);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// boofcv-ip front end
+// ---------------------------------------------------------------------------------------------------------------
+static int convHost(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride,
+					int width, int height, float* out, int outStart, int outStride) {
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, width, height);
+	if (!kernel) return bhip_fail(ctx, BHIP_ERR_INVALID, "null kernel");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	// the no-border variants leave the frame of `out` untouched: start from the caller's pixels
+	BHIP_TRY(uploadImage(ctx, sc->b, out, outStart, outStride, width, height));
+	BHIP_TRY(bhip_launch_conv(ctx, vertical, normalized, kernel, kw, koff, sc->a.as<float>(), width, width, height, sc->b.as<float>(), width));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, width, height);
+}
+int bhip_conv_h_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride, int width, int height, float* out,
+					int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	return convHost(ctx, false, false, kernel, kw, koff, in, inStart, inStride, width, height, out, outStart, outStride);
+}
+int bhip_conv_v_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride, int width, int height, float* out,
+					int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	return convHost(ctx, true, false, kernel, kw, koff, in, inStart, inStride, width, height, out, outStart, outStride);
+}
+int bhip_conv_norm_h_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride, int width, int height,
+						 float* out, int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	return convHost(ctx, false, true, kernel, kw, koff, in, inStart, inStride, width, height, out, outStart, outStride);
+}
+int bhip_conv_norm_v_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride, int width, int height,
+						 float* out, int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	return convHost(ctx, true, true, kernel, kw, koff, in, inStart, inStride, width, height, out, outStart, outStride);
+}
+
+int bhip_gaussian_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, double sigma, int radius, float* out,
+					  int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, width, height);
+	if (sigma <= 0 && radius <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Sigma must be > 0");
+	std::vector<float> k = bhip_gaussian1d_f32(sigma, radius);
+	const int kw = (int)k.size(), koff = kw / 2;
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)width * height * 4));
+	BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, sc->a.as<float>(), width, width, height, sc->b.as<float>(), width));
+	BHIP_TRY(bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->b.as<float>(), width, width, height, sc->c.as<float>(), width));
+	return downloadImage(ctx, sc->c.p, out, outStart, outStride, width, height);
+}
+
+static int gradHost(bhip_ctx* ctx, int kind, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,
+					int outStride, int border) {
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, dx, outStride, width, height);
+	CHECK_IMG(ctx, dy, outStride, width, height);
+	if (border != 0 && border != 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "border policy not supported on the GPU");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(uploadImage(ctx, sc->b, dx, outStart, outStride, width, height));
+	BHIP_TRY(uploadImage(ctx, sc->c, dy, outStart, outStride, width, height));
+	BHIP_TRY(bhip_launch_gradient(ctx, kind, sc->a.as<float>(), width, width, height, sc->b.as<float>(), sc->c.as<float>(), width, border));
+	BHIP_TRY(downloadImage(ctx, sc->b.p, dx, outStart, outStride, width, height));
+	return downloadImage(ctx, sc->c.p, dy, outStart, outStride, width, height);
+}
+int bhip_sobel_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart, int outStride,
+				   int border) {
+	CHECK_CTX(ctx);
+	return gradHost(ctx, 0, in, inStart, inStride, width, height, dx, dy, outStart, outStride, border);
+}
+int bhip_three_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart, int outStride,
+				   int border) {
+	CHECK_CTX(ctx);
+	return gradHost(ctx, 1, in, inStart, inStride, width, height, dx, dy, outStart, outStride, border);
+}
+
+int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int width, int height, int radius, int numPoints,
+				   const int32_t* samplePoints, const int32_t* compare, const double* xy, int n, int32_t* out) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, img, stride, width, height);
+	if (numPoints <= 0 || !samplePoints || !compare || n < 0 || (n > 0 && (!xy || !out))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad BRIEF arguments");
+	if (n == 0) return BHIP_OK;
+	const int words = (numPoints + 31) / 32;
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, img, start, stride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)numPoints * 16));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)n * 16));
+	BHIP_TRY(sc->e.reserve(ctx, (size_t)n * words * 4));
+	int* dsp = sc->b.as<int>();
+	int* dcp = dsp + 2 * numPoints;
+	BHIP_HIP(ctx, hipMemcpyAsync(dsp, samplePoints, (size_t)numPoints * 8, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(dcp, compare, (size_t)numPoints * 8, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(sc->c.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_TRY(bhip_launch_brief(ctx, sc->a.as<float>(), width, width, height, radius, numPoints, dsp, dcp, sc->c.as<double>(), n, sc->e.as<int>()));
+	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->e.p, (size_t)n * words * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
+}  // extern "C"

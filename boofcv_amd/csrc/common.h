@@ -1,0 +1,137 @@
+// Internal declarations shared by the HIP translation units of libboofhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+#include "../../include/boofhip.h"
+
+#define BHIP_WAVE 64
+
+struct bhip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	std::string error;
+	// small pinned staging buffer for count read-backs
+	int* hostScratch = nullptr;
+};
+
+static inline int bhip_fail(bhip_ctx* ctx, int code, const std::string& msg) {
+	if (ctx) ctx->error = msg;
+	return code;
+}
+
+#define BHIP_HIP(ctx, expr)                                                                                                      \
+	do {                                                                                                                         \
+		hipError_t _e = (expr);                                                                                                  \
+		if (_e != hipSuccess) return bhip_fail((ctx), _e == hipErrorOutOfMemory ? BHIP_ERR_NOMEM : BHIP_ERR_HIP,                 \
+											   std::string(#expr) + ": " + hipGetErrorString(_e));                               \
+	} while (0)
+
+#define BHIP_TRY(expr)                 \
+	do {                               \
+		int _s = (expr);               \
+		if (_s != BHIP_OK) return _s;  \
+	} while (0)
+
+// grow-only device buffer
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	int reserve(bhip_ctx* ctx, size_t bytes) {
+		if (bytes <= cap) return BHIP_OK;
+		if (p) { BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream)); BHIP_HIP(ctx, hipFree(p)); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8;
+		BHIP_HIP(ctx, hipMalloc(&p, want));
+		cap = want;
+		return BHIP_OK;
+	}
+	void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+	template <class T> T* as() const { return (T*)p; }
+};
+
+// ---------------- image view passed to kernels ----------------
+struct ImgView {
+	const float* data;   // base of image 0 (already offset by startIndex)
+	long long imageStride;  // floats between images of a batch
+	int stride;          // floats between rows
+	int width, height;
+};
+struct ImgViewW {
+	float* data;
+	long long imageStride;
+	int stride;
+	int width, height;
+};
+
+// ---------------- detector structures ----------------
+#define BHIP_MAX_OCTAVES 8
+#define BHIP_MAX_LEVELS 8
+
+struct KeyPoint {      // one detected interest point, as stored on the device
+	double x, y, scale;
+	unsigned int key;    // bit index in the per-image candidate bitmap == rank key (octave, level, blockY, blockX)
+	unsigned int pad;
+};
+
+// tables for orientation + descriptor, resident in device memory
+struct SurfTables {
+	// orientation
+	int oriStable;           // 1 sliding window, 0 average
+	int oriRadius;           // sampleRadius
+	int oriWidth;            // 2*radius+1
+	int oriKernelWidth;      // ConfigOrientation.sampleWidth
+	int oriHasWeights;
+	double oriPeriod;        // samplePeriod
+	double oriWindow;        // windowSize
+	double oriRadiusToScale; // objectRadiusToScale
+	const double* oriWeights;  // oriWidth^2
+	// descriptor
+	int stable;              // 1 DescribePointSurfMod, 0 DescribePointSurf
+	int widthLargeGrid, widthSubRegion, widthSample, overLap;
+	int dof;
+	int radiusDescriptor;
+	const double* weightSub;   // (sub+2*overlap)^2        (stable)
+	const double* weightGrid;  // largeGrid^2              (stable)
+	const double* weightFast;  // (largeGrid*sub)^2        (fast)
+};
+
+// host-side Gaussian tables (tables.cpp): product code, independent of oracle/
+std::vector<double> bhip_gaussian2d_f64(double sigma, int radius);          // FactoryKernelGaussian.gaussian(2,true,64,sigma,radius)
+std::vector<double> bhip_gaussian_width(double sigma, int width);           // FactoryKernelGaussian.gaussianWidth
+std::vector<float> bhip_gaussian1d_f32(double sigma, int radius);           // FactoryKernelGaussian.gaussian(Kernel1D_F32,sigma,radius)
+
+// ---------------- kernel launchers (defined in the .hip files) ----------------
+int bhip_launch_integral(bhip_ctx* ctx, ImgView in, ImgViewW out, int batch);
+int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
+						long long imageStrideOut, int outStride);
+
+struct DetectLevelParams {
+	int skip, w, h;              // intensity image size
+	int sizeLower, sizeMid, sizeUpper;  // kernel sizes of level-1, level, level+1
+	int border;                  // ignoreBorder = size/(2*skip)
+	int nbx, nby;                // blocks in the NMS region
+	unsigned int bitBase;        // first bit of this (octave,level) in the per-image bitmap
+};
+int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
+							   DetectLevelParams p, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
+							   int cap);
+int bhip_launch_rank_scatter(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, unsigned int* wordPrefix, const KeyPoint* cand,
+							 const int* candCount, int cap, int batch, KeyPoint* sorted);
+int bhip_launch_nonmax_only(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border, unsigned int* bitmap,
+							int bitmapWords, int nbx, int nby);
+int bhip_launch_bitmap_to_xy(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border,
+							 const unsigned int* bitmap, const unsigned int* wordPrefix, int bitmapWords, int nbx, int nby, int16_t* xy, int cap);
+int bhip_launch_word_prefix(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, int batch, unsigned int* wordPrefix, int* totals);
+
+int bhip_launch_describe(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, const int* kpImage /*may be null: use imageOfBlock*/, long long total,
+						 const int* imageStart /*batch+1 prefix of counts*/, int batch, SurfTables t, double* angles, double* desc, uint8_t* white);
+
+int bhip_launch_assoc_l2(bhip_ctx* ctx, const double* src, int ns, const double* dst, int nd, int dof, double maxErr, int backwards, int sqrtScore,
+						 int* pairs, double* fit, DevBuf& work);
+int bhip_launch_assoc_hamming(bhip_ctx* ctx, const int32_t* src, int ns, const int32_t* dst, int nd, int words, double maxErr, int backwards,
+							  int* pairs, double* fit, DevBuf& work);

@@ -1,0 +1,230 @@
+// K3: strict block non-maximum suppression + 3x3x3 scale-space test + sub-pixel fit + ordered compaction.
+//
+// Reference:
+//   NonMaxBlock.process                       F:alg/feature/detect/extract/NonMaxBlock.java:69-94
+//   NonMaxBlockSearchStrict.Max.searchBlock   F:alg/feature/detect/extract/NonMaxBlockSearchStrict.java:56-79, checkLocalMax :196-221
+//   FastHessianFeatureDetector.findLocalScaleSpaceMax :230-298, checkMax :304-313, polyPeak :336-350
+//       (F:alg/feature/detect/interest/FastHessianFeatureDetector.java)
+//
+// The block algorithm accepts, per (r+1)^2 block, the first strict block maximum iff it is >= threshold, != Float.MAX_VALUE and no other
+// pixel of its (2r+1)^2 neighbourhood (clamped to the image) is >= it.  A pixel passing the neighbourhood test is necessarily the unique
+// maximum of its block, so the accepted set is "all strict (2r+1)^2 maxima inside the ignore border" and the reference's output order
+// (USE_CONCURRENT=false) is block-raster order.  Each pixel is tested by one thread; an accepted pixel sets bit (blockY*nbx+blockX) of a
+// per-image bitmap, which makes the ordering a popcount-prefix: rank = #bits below.  No sort, no atomics on the ordering path.
+// fp32 compares only, so keypoint indices are bit-exact whenever the intensity image is.
+#include "common.h"
+#include <cfloat>
+
+// strict-maximum test of NonMaxBlockSearchStrict.Max for pixel (x,y) with value v
+__device__ __forceinline__ bool strictLocalMax(const float* __restrict__ img, int stride, int w, int h, int x, int y, int r, float v, float thr) {
+	if (!(v >= thr) || v == FLT_MAX) return false;
+	const int x0 = max(x - r, 0), x1 = min(x + r, w - 1), y0 = max(y - r, 0), y1 = min(y + r, h - 1);
+	for (int j = y0; j <= y1; j++) {
+		const float* row = img + (long long)j * stride;
+		for (int i = x0; i <= x1; i++) {
+			if (row[i] >= v && !(i == x && j == y)) return false;
+		}
+	}
+	return true;
+}
+
+__device__ __forceinline__ float polyPeak(float lower, float middle, float upper) {
+	const float a = 0.5f * lower - middle + 0.5f * upper;
+	const float b = 0.5f * upper - 0.5f * lower;
+	if (a == 0.0f) return 0.0f;
+	return -b / (2.0f * a);
+}
+
+struct NmsParams {
+	const float* lower;
+	const float* mid;
+	const float* upper;
+	long long imageStride;
+	int stride;
+	DetectLevelParams p;
+	int radius;
+	float threshold;
+	unsigned int* bitmap;
+	int bitmapWords;
+	KeyPoint* cand;
+	int* candCount;
+	int cap;
+};
+
+__global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
+	const int b = P.p.border;
+	const int w = P.p.w, h = P.p.h;
+	const int x = b + blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = b + blockIdx.y;
+	const int img = blockIdx.z;
+	if (x >= w - b || y >= h - b) return;
+	const float* mid = P.mid + (long long)img * P.imageStride;
+	const int stride = P.stride;
+	const int r = P.radius;
+	const float val = mid[(long long)y * stride + x];
+	if (!strictLocalMax(mid, stride, w, h, x, y, r, val, P.threshold)) return;
+
+	// findLocalScaleSpaceMax: candidates hugging the ignore border are dropped
+	const int ignoreR = b + r;
+	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) return;
+	const float* lower = P.lower + (long long)img * P.imageStride;
+	const float* upper = P.upper + (long long)img * P.imageStride;
+	// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
+	for (int j = y - 1; j <= y + 1; j++)
+		for (int i = x - 1; i <= x + 1; i++) {
+			const bool in = i >= 0 && i < w && j >= 0 && j < h;
+			const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
+			const float up = in ? upper[(long long)j * stride + i] : 0.0f;
+			if (lo >= val || up >= val) return;
+		}
+	const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
+	const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
+	const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
+	const float interpX = ((float)x + peakX) * (float)P.p.skip;
+	const float interpY = ((float)y + peakY) * (float)P.p.skip;
+	const float interpS = (float)P.p.sizeMid + peakS * (float)(P.p.sizeMid - P.p.sizeLower);
+	const double scale = 1.2 * (double)interpS / 9.0;
+
+	const int step = r + 1;
+	const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
+	atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+	const int slot = atomicAdd(&P.candCount[img], 1);
+	if (slot < P.cap) {
+		KeyPoint kp;
+		kp.x = (double)interpX;
+		kp.y = (double)interpY;
+		kp.scale = scale;
+		kp.key = bit;
+		kp.pad = 0;
+		P.cand[(long long)img * P.cap + slot] = kp;
+	}
+}
+
+int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
+							   DetectLevelParams p, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
+							   int cap) {
+	const int rw = p.w - 2 * p.border, rh = p.h - 2 * p.border;
+	if (rw <= 0 || rh <= 0) return BHIP_OK;
+	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap};
+	dim3 grid((rw + 255) / 256, rh, batch);
+	hipLaunchKernelGGL(k_nms_scalespace, grid, dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---- exclusive prefix of per-word popcounts: one workgroup per image ----
+__global__ __launch_bounds__(1024) void k_word_prefix(const unsigned int* __restrict__ bitmap, int words, unsigned int* __restrict__ prefix, int* __restrict__ totals) {
+	__shared__ unsigned int waveSum[16];
+	__shared__ unsigned int carry;
+	const int img = blockIdx.x;
+	const unsigned int* bm = bitmap + (long long)img * words;
+	unsigned int* pf = prefix + (long long)img * words;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int base = 0; base < words; base += 1024) {
+		const int i = base + threadIdx.x;
+		const unsigned int c = i < words ? __popc(bm[i]) : 0u;
+		// inclusive scan inside the wave
+		unsigned int s = c;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned int t = __shfl_up(s, o, 64);
+			if (lane >= o) s += t;
+		}
+		if (lane == 63) waveSum[wave] = s;
+		__syncthreads();
+		unsigned int off = carry;
+		for (int k = 0; k < wave; k++) off += waveSum[k];
+		if (i < words) pf[i] = off + s - c;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = off + s;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0 && totals) totals[img] = (int)carry;
+}
+
+int bhip_launch_word_prefix(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, int batch, unsigned int* wordPrefix, int* totals) {
+	if (batch <= 0 || bitmapWords <= 0) return BHIP_OK;
+	hipLaunchKernelGGL(k_word_prefix, dim3(batch), dim3(1024), 0, ctx->stream, bitmap, bitmapWords, wordPrefix, totals);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---- scatter the unordered candidates to their block-raster rank ----
+__global__ __launch_bounds__(256) void k_rank_scatter(const unsigned int* __restrict__ bitmap, int words, const unsigned int* __restrict__ prefix,
+													   const KeyPoint* __restrict__ cand, const int* __restrict__ candCount, int cap,
+													   KeyPoint* __restrict__ sorted) {
+	const int img = blockIdx.y;
+	const int n = min(candCount[img], cap);
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const KeyPoint kp = cand[(long long)img * cap + i];
+	const unsigned int word = kp.key >> 5, bit = kp.key & 31;
+	const unsigned int below = bitmap[(long long)img * words + word] & ((1u << bit) - 1u);
+	const unsigned int rank = prefix[(long long)img * words + word] + __popc(below);
+	sorted[(long long)img * cap + rank] = kp;
+}
+
+int bhip_launch_rank_scatter(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, unsigned int* wordPrefix, const KeyPoint* cand,
+							 const int* candCount, int cap, int batch, KeyPoint* sorted) {
+	if (batch <= 0 || cap <= 0) return BHIP_OK;
+	dim3 grid((cap + 255) / 256, batch);
+	hipLaunchKernelGGL(k_rank_scatter, grid, dim3(256), 0, ctx->stream, bitmap, bitmapWords, (const unsigned int*)wordPrefix, cand, candCount, cap, sorted);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---- stand-alone NMS (BOverrideFactoryFeatureExtractor.nonmax / parity tests) ----
+__global__ __launch_bounds__(256) void k_nonmax_only(const float* __restrict__ img, int stride, int w, int h, int radius, float thr, int border,
+													  unsigned int* __restrict__ bitmap, int nbx) {
+	const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = border + blockIdx.y;
+	if (x >= w - border || y >= h - border) return;
+	const float v = img[(long long)y * stride + x];
+	if (!strictLocalMax(img, stride, w, h, x, y, radius, v, thr)) return;
+	const int step = radius + 1;
+	const unsigned int bit = (unsigned)((y - border) / step) * (unsigned)nbx + (unsigned)((x - border) / step);
+	atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+}
+
+int bhip_launch_nonmax_only(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border, unsigned int* bitmap,
+							int bitmapWords, int nbx, int nby) {
+	(void)bitmapWords; (void)nby;
+	const int rw = w - 2 * border, rh = h - 2 * border;
+	if (rw <= 0 || rh <= 0) return BHIP_OK;
+	dim3 grid((rw + 255) / 256, rh);
+	hipLaunchKernelGGL(k_nonmax_only, grid, dim3(256), 0, ctx->stream, img, stride, w, h, radius, threshold, border, bitmap, nbx);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// second pass of the stand-alone NMS: every accepted pixel writes its (x,y) at its block-raster rank
+__global__ __launch_bounds__(256) void k_bitmap_to_xy(const float* __restrict__ img, int stride, int w, int h, int radius, float thr, int border,
+													   const unsigned int* __restrict__ bitmap, const unsigned int* __restrict__ prefix, int nbx,
+													   int16_t* __restrict__ xy, int cap) {
+	const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = border + blockIdx.y;
+	if (x >= w - border || y >= h - border) return;
+	const float v = img[(long long)y * stride + x];
+	if (!strictLocalMax(img, stride, w, h, x, y, radius, v, thr)) return;
+	const int step = radius + 1;
+	const unsigned int bit = (unsigned)((y - border) / step) * (unsigned)nbx + (unsigned)((x - border) / step);
+	const unsigned int word = bit >> 5;
+	const unsigned int rank = prefix[word] + __popc(bitmap[word] & ((1u << (bit & 31)) - 1u));
+	if ((int)rank < cap) {
+		xy[2 * rank] = (int16_t)x;
+		xy[2 * rank + 1] = (int16_t)y;
+	}
+}
+
+int bhip_launch_bitmap_to_xy(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border,
+							 const unsigned int* bitmap, const unsigned int* wordPrefix, int bitmapWords, int nbx, int nby, int16_t* xy, int cap) {
+	(void)bitmapWords; (void)nby;
+	const int rw = w - 2 * border, rh = h - 2 * border;
+	if (rw <= 0 || rh <= 0) return BHIP_OK;
+	dim3 grid((rw + 255) / 256, rh);
+	hipLaunchKernelGGL(k_bitmap_to_xy, grid, dim3(256), 0, ctx->stream, img, stride, w, h, radius, threshold, border, bitmap, wordPrefix, nbx, xy, cap);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}

@@ -1,0 +1,240 @@
+// K8-K10: boofcv-ip front-end ops behind the BOverride* hooks (separable convolution, Gaussian blur, Sobel / three-tap gradient)
+// and the BRIEF binary descriptor.  All fp32 with the reference's evaluation order and no FMA contraction.
+//
+// Reference:
+//   ConvolveImageNoBorder.horizontal/vertical     I:alg/filter/convolve/ConvolveImageNoBorder.java:53-77
+//     unrolled widths 3,5,7,9,11 (first tap assigns)  I:alg/filter/convolve/noborder/ConvolveImageUnrolled_SB_F32_F32.java:50-150,152-180,347-382
+//     standard (total = 0 first)                      I:alg/filter/convolve/noborder/ConvolveImageStandard_SB.java:44-104
+//   ConvolveImageNormalized.horizontal/vertical   I:alg/filter/convolve/ConvolveImageNormalized.java:48-93
+//     border re-normalisation                         I:alg/filter/convolve/normalized/ConvolveNormalized_JustBorder_SB.java:42-145
+//     kernel wider than the image                     I:alg/filter/convolve/normalized/ConvolveNormalizedNaive_SB.java:37-84
+//   GradientSobel_UnrolledOuter.process_F32_sub   I:alg/filter/derivative/impl/GradientSobel_UnrolledOuter.java:210-
+//   GradientThree_Standard.process                I:alg/filter/derivative/impl/GradientThree_Standard.java:40-62
+//   border handling                               I:alg/filter/convolve/border/ConvolveJustBorder_General_SB.java:46-175,
+//                                                 I:alg/filter/derivative/DerivativeHelperFunctions.java:140-175
+//   ImplDescribeBinaryCompare_F32                 F:alg/feature/describe/impl/ImplDescribeBinaryCompare_F32.java:47-101
+// Bound: HBM (8P bytes per separable pass, 12P for a gradient); taps are re-read through L1/L2.
+#include "common.h"
+
+#define BHIP_MAX_TAPS 255
+
+struct ConvParams {
+	const float* in;
+	float* out;
+	int inStride, outStride, width, height;
+	int kw, koff;
+	int unrolled;   // first tap assigns instead of adding to 0
+	int mode;       // 0 = no border (frame untouched), 1 = normalised border, 2 = normalised naive (kernel wider than image)
+	float k[BHIP_MAX_TAPS];
+};
+
+template <bool VERTICAL>
+__global__ __launch_bounds__(256) void k_conv(ConvParams P) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	const int y = blockIdx.y;
+	if (x >= P.width) return;
+	const int pos = VERTICAL ? y : x;
+	const int extent = VERTICAL ? P.height : P.width;
+	const int offL = P.koff, offR = P.kw - P.koff - 1;
+	const long long step = VERTICAL ? P.inStride : 1;
+	const float* src = P.in + (long long)y * P.inStride + x;
+	const bool interior = pos >= offL && pos < extent - offR;
+	float result;
+	if (interior && P.mode != 2) {
+		const float* s = src - offL * step;
+		float total;
+		if (P.unrolled) {
+			total = s[0] * P.k[0];
+			for (int k = 1; k < P.kw; k++) total += s[k * step] * P.k[k];
+		} else {
+			total = 0;
+			for (int k = 0; k < P.kw; k++) total += s[k * step] * P.k[k];
+		}
+		result = total;
+	} else {
+		if (P.mode == 0) return;
+		const int k0 = max(0, offL - pos);
+		const int k1 = min(P.kw, extent - pos + offL);
+		float total = 0, weight = 0;
+		for (int k = k0; k < k1; k++) {
+			const float w = P.k[k];
+			weight += w;
+			total += src[(long long)(k - offL) * step] * w;
+		}
+		result = total / weight;
+	}
+	P.out[(long long)y * P.outStride + x] = result;
+}
+
+int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
+					 int height, float* out, int outStride) {
+	if (kw <= 0 || kw > BHIP_MAX_TAPS || koff < 0 || koff >= kw) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "kernel width not supported");
+	if (width <= 0 || height <= 0) return BHIP_OK;
+	ConvParams P;
+	P.in = in; P.out = out; P.inStride = inStride; P.outStride = outStride; P.width = width; P.height = height; P.kw = kw; P.koff = koff;
+	for (int i = 0; i < kw; i++) P.k[i] = kernel[i];
+	P.unrolled = (koff == kw / 2 && kw % 2 == 1 && (kw == 3 || kw == 5 || kw == 7 || kw == 9 || kw == 11)) ? 1 : 0;
+	P.mode = 0;
+	if (normalized) {
+		const int extent = vertical ? height : width;
+		if (kw >= extent) {
+			P.mode = 2;
+		} else {
+			P.mode = 1;
+			// ConvolveImageNormalized: re-normalise when |sum - 1| > 1e-4 (Kernel1D_F32.computeSum is a sequential fp32 sum)
+			float sum = 0;
+			for (int i = 0; i < kw; i++) sum += P.k[i];
+			float diff = sum - 1.0f;
+			if (diff < 0) diff = -diff;
+			if (diff > 1e-4f) {
+				float total = 0;
+				for (int i = 0; i < kw; i++) total += P.k[i];
+				for (int i = 0; i < kw; i++) P.k[i] /= total;
+			}
+		}
+	}
+	dim3 grid((width + 255) / 256, height);
+	if (vertical) hipLaunchKernelGGL(k_conv<true>, grid, dim3(256), 0, ctx->stream, P);
+	else hipLaunchKernelGGL(k_conv<false>, grid, dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---------------- gradients ----------------
+struct GradParams {
+	const float* in;
+	float* dx;
+	float* dy;
+	int inStride, outStride, width, height;
+	int border;  // 0: frame untouched, 1: ImageBorderValue(0)
+};
+
+__device__ __forceinline__ float at0(const GradParams& P, int x, int y) {
+	return (x >= 0 && x < P.width && y >= 0 && y < P.height) ? P.in[(long long)y * P.inStride + x] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_sobel(GradParams P) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= P.width) return;
+	const long long o = (long long)y * P.outStride + x;
+	if (x >= 1 && x < P.width - 1 && y >= 1 && y < P.height - 1) {
+		const float* c = P.in + (long long)y * P.inStride + x;
+		const int s = P.inStride;
+		const float a11 = c[-s - 1], a12 = c[-s], a13 = c[-s + 1];
+		const float a21 = c[-1], a23 = c[1];
+		const float a31 = c[s - 1], a32 = c[s], a33 = c[s + 1];
+		const float v = (a33 - a11) * 0.25f;
+		const float w = (a31 - a13) * 0.25f;
+		P.dy[o] = (a32 - a12) * 0.5f + v + w;
+		P.dx[o] = (a23 - a21) * 0.5f + v - w;
+	} else if (P.border) {
+		// generic border convolution with GradientSobel.kernelDerivX/Y_F32: total = 0; total += get(x+j,y+i)*k in row-major kernel order
+		const float kx[9] = {-0.25f, 0, 0.25f, -0.5f, 0, 0.5f, -0.25f, 0, 0.25f};
+		const float ky[9] = {-0.25f, -0.5f, -0.25f, 0, 0, 0, 0.25f, 0.5f, 0.25f};
+		float tx = 0, ty = 0;
+		int ik = 0;
+		for (int i = -1; i <= 1; i++)
+			for (int j = -1; j <= 1; j++, ik++) {
+				const float p = at0(P, x + j, y + i);
+				tx += p * kx[ik];
+				ty += p * ky[ik];
+			}
+		P.dx[o] = tx;
+		P.dy[o] = ty;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_three(GradParams P) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= P.width) return;
+	const long long o = (long long)y * P.outStride + x;
+	const int W = P.width, H = P.height;
+	const float* c = P.in + (long long)y * P.inStride + x;
+	const int s = P.inStride;
+	const bool interior = x >= 1 && x < W - 1 && y >= 1 && y < H - 1;
+	if (!P.border) {
+		if (interior) {
+			P.dx[o] = (c[1] - c[-1]) * 0.5f;
+			P.dy[o] = (c[s] - c[-s]) * 0.5f;
+		}
+		return;
+	}
+	const float k0 = -0.5f, k1 = 0.0f, k2 = 0.5f;
+	// derivX: generic border form on the first/last column, unrolled 3-tap form on rows {0,1,H-2,H-1}, else the interior expression
+	float dx, dy;
+	if (x == 0 || x == W - 1) {
+		float t = 0;
+		t += at0(P, x - 1, y) * k0; t += at0(P, x, y) * k1; t += at0(P, x + 1, y) * k2;
+		dx = t;
+	} else if (y <= 1 || y >= H - 2) {
+		float t = c[-1] * k0; t += c[0] * k1; t += c[1] * k2;
+		dx = t;
+	} else {
+		dx = (c[1] - c[-1]) * 0.5f;
+	}
+	if (y == 0 || y == H - 1) {
+		float t = 0;
+		t += at0(P, x, y - 1) * k0; t += at0(P, x, y) * k1; t += at0(P, x, y + 1) * k2;
+		dy = t;
+	} else if (x <= 1 || x >= W - 2) {
+		float t = c[-s] * k0; t += c[0] * k1; t += c[s] * k2;
+		dy = t;
+	} else {
+		dy = (c[s] - c[-s]) * 0.5f;
+	}
+	P.dx[o] = dx;
+	P.dy[o] = dy;
+}
+
+int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border) {
+	if (width <= 0 || height <= 0) return BHIP_OK;
+	GradParams P{in, dx, dy, inStride, outStride, width, height, border};
+	dim3 grid((width + 255) / 256, height);
+	if (kind == 0) hipLaunchKernelGGL(k_sobel, grid, dim3(256), 0, ctx->stream, P);
+	else hipLaunchKernelGGL(k_three, grid, dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---------------- BRIEF ----------------
+struct BriefParams {
+	const float* img;
+	int stride, width, height, radius, numPoints, words, n;
+	const int* samplePoints;  // [numPoints][2]
+	const int* compare;       // [numPoints][2]
+	const double* xy;         // [n][2]
+	int* out;                 // [n][words]
+};
+
+// one thread = one 32-pair word of one key point
+__global__ __launch_bounds__(256) void k_brief(BriefParams P) {
+	const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= (long long)P.n * P.words) return;
+	const int p = (int)(t / P.words), word = (int)(t - (long long)p * P.words);
+	const int c_x = (int)P.xy[2 * p], c_y = (int)P.xy[2 * p + 1];
+	const bool inside = !(c_x - P.radius < 0 || c_x + P.radius >= P.width || c_y - P.radius < 0 || c_y + P.radius >= P.height);
+	const int i0 = word * 32, i1 = min(P.numPoints, i0 + 32);
+	unsigned int desc = 0;
+	for (int j = i0; j < i1; j++) {
+		const int ia = P.compare[2 * j], ib = P.compare[2 * j + 1];
+		const int ax = P.samplePoints[2 * ia] + c_x, ay = P.samplePoints[2 * ia + 1] + c_y;
+		const int bx = P.samplePoints[2 * ib] + c_x, by = P.samplePoints[2 * ib + 1] + c_y;
+		const bool ok = inside || (ax >= 0 && ax < P.width && ay >= 0 && ay < P.height && bx >= 0 && bx < P.width && by >= 0 && by < P.height);
+		if (ok) {
+			const float va = P.img[(long long)ay * P.stride + ax];
+			const float vb = P.img[(long long)by * P.stride + bx];
+			desc = desc * 2u + (va < vb ? 1u : 0u);
+		}
+	}
+	P.out[t] = (int)desc;
+}
+
+int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
+					  const int* compare, const double* xy, int n, int* out) {
+	if (n <= 0) return BHIP_OK;
+	BriefParams P{img, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out};
+	const long long total = (long long)n * P.words;
+	hipLaunchKernelGGL(k_brief, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}

@@ -1,0 +1,205 @@
+/*
+ * boofhip.h -- C ABI of libboofhip.so, the MI355X (gfx950) provider for BoofCV's
+ * detect -> describe -> associate hot path.
+ *
+ * This is the drop-in boundary: every entry point below is what a JNI shim for the reference would bind
+ * (see INTEGRATION.md for the Java side).  Citations name the reference interface each function replaces;
+ * abbreviations (paths under the reference tree):
+ *   F: = main/boofcv-feature/src/main/java/boofcv/    I: = main/boofcv-ip/src/main/java/boofcv/
+ *   T: = main/boofcv-types/src/main/java/boofcv/
+ *
+ * Conventions
+ *  - plain C, no C++ or torch types; the caller owns every host buffer, the library owns device memory;
+ *  - every function returns 0 (BHIP_OK) or a negative bhip_status and never throws or aborts;
+ *    bhip_last_error(ctx) gives the message.  A Java shim turns a non-zero status into RuntimeException,
+ *    which is the reference's own "override did not handle it, run the Java code" signal
+ *    (I:alg/filter/convolve/BOverrideConvolveImage.java:53-62);
+ *  - one bhip_ctx per host thread per device; calls on one ctx are serialised on one HIP stream
+ *    (reference objects are not thread safe either: one instance per thread);
+ *  - images are GrayF32: pixel (x,y) = data[startIndex + y*stride + x]  (T:struct/image/ImageBase.java:34-52),
+ *    so sub-images (startIndex != 0, stride > width) work everywhere;
+ *  - pointers named dev_* are device (HBM) addresses on the ctx's device; every other pointer is host memory;
+ *  - there is no CPU fallback inside the library: without a usable GPU bhip_ctx_create fails.
+ */
+#ifndef BOOFHIP_H
+#define BOOFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+	BHIP_OK = 0,
+	BHIP_ERR_INVALID = -1,     /* bad argument / shape (IllegalArgumentException in the reference) */
+	BHIP_ERR_UNSUPPORTED = -2, /* configuration not implemented on the GPU: caller should use the Java path */
+	BHIP_ERR_HIP = -3,         /* HIP runtime error (message has the hipError string) */
+	BHIP_ERR_NOMEM = -4,
+	BHIP_ERR_CAPACITY = -5     /* internal fixed-capacity list overflowed even after regrow */
+} bhip_status;
+
+typedef struct bhip_ctx bhip_ctx;
+typedef struct bhip_surf bhip_surf;
+
+/* ---- configuration structs: same field names and defaults as the reference's Config* classes ---- */
+
+/* F:abst/feature/detect/interest/ConfigFastHessian.java:33-70 */
+typedef struct {
+	float detectThreshold;     /* 1 */
+	int extractRadius;         /* 2 */
+	int maxFeaturesPerScale;   /* -1 (>0 is BHIP_ERR_UNSUPPORTED: ddogleg QuickSelect order is unpinned) */
+	int initialSampleSize;     /* 1 */
+	int initialSize;           /* 9 */
+	int numberScalesPerOctave; /* 4 */
+	int numberOfOctaves;       /* 4 */
+	int scaleStepSize;         /* 6 */
+} bhip_fh_cfg;
+
+/* F:abst/feature/describe/ConfigSurfDescribe.java:34-78 (Speed and Stability merged; useHaar=false only) */
+typedef struct {
+	int widthLargeGrid;    /* 4 */
+	int widthSubRegion;    /* 5 */
+	int widthSample;       /* 3 */
+	double weightSigma;    /* Speed: 4.5 */
+	int overLap;           /* Stability: 2 */
+	double sigmaLargeGrid; /* Stability: 2.5 */
+	double sigmaSubRegion; /* Stability: 2.5 */
+} bhip_surf_cfg;
+
+/* F:abst/feature/orientation/ConfigSlidingIntegral.java:34-54 (stable) /
+ * ConfigAverageIntegral.java:34-51 (fast; windowSize ignored) */
+typedef struct {
+	double objectRadiusToScale; /* 1/BoofDefaults.SURF_SCALE_TO_RADIUS = 0.5 */
+	double samplePeriod;        /* sliding 0.65, average 1 */
+	double windowSize;          /* sliding pi/3 */
+	int radius;                 /* sliding 8, average 6 */
+	double weightSigma;         /* -1 */
+	int sampleWidth;            /* 6 */
+} bhip_ori_cfg;
+
+void bhip_fh_cfg_default(bhip_fh_cfg* c);
+void bhip_surf_cfg_default(bhip_surf_cfg* c);
+void bhip_ori_cfg_default(bhip_ori_cfg* c, int stable);
+
+/* ---- context ---- */
+int bhip_ctx_create(int device, bhip_ctx** out);
+/* same, but run on an existing hipStream_t (e.g. torch's current stream) instead of a private one */
+int bhip_ctx_create_on_stream(int device, void* hip_stream, bhip_ctx** out);
+int bhip_ctx_destroy(bhip_ctx* ctx);
+int bhip_ctx_synchronize(bhip_ctx* ctx);
+const char* bhip_last_error(bhip_ctx* ctx);
+const char* bhip_version(void);
+
+/* ---- detect + describe: FactoryDetectDescribe.surfStable / surfFast -> DetectDescribePoint<GrayF32,BrightFeature>
+ *      (F:factory/feature/detdesc/FactoryDetectDescribe.java:118-135,209-226; F:abst/feature/detdesc/DetectDescribePoint.java:32-46;
+ *       F:abst/feature/detdesc/WrapDetectDescribeSurf.java:93-159).  NULL config = reference defaults. ---- */
+int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out);
+int bhip_surf_destroy(bhip_surf* s);
+/* detect(T input) on a batch of host images (batch = 1 is the reference call).  Results are recycled by the next detect,
+ * as in the reference (DetectDescribePoint.java:38-40). */
+int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* startIndex, const int* stride, int width, int height, int batch);
+/* same on a device-resident batch: image i starts at dev_images + i*imageStride floats, rows are `stride` floats apart.
+ * Asynchronous on the ctx stream apart from one small count read-back. */
+int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long imageStride, int stride, int width, int height, int batch);
+/* getNumberOfFeatures() */
+int bhip_surf_count(bhip_surf* s, int image, int* n);
+/* getLocation(i)/scale -> xy_scale[3n] ; getOrientation(i) -> angle[n] ; BrightFeature.white -> white[n] ;
+ * getDescription(i).value -> desc[64n].  getRadius(i) = scale*2 (BoofDefaults.SURF_SCALE_TO_RADIUS).  Any pointer may be NULL. */
+int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, uint8_t* white, double* desc);
+/* device views of the same results (valid until the next detect): descriptors [n][dof] doubles, laplacian signs [n] bytes */
+int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const double** dev_xy_scale, const uint8_t** dev_white, int* n);
+int bhip_surf_dof(bhip_surf* s);
+/* total key points over the whole batch of the last detect */
+int bhip_surf_total(bhip_surf* s, long long* n);
+
+/* stage-level entry points of the detector (used by the parity tests and by the BOverride nonmax hook) */
+/* describe externally supplied points (x,y,scale) on the integral image of image `image` of the last detect:
+ * WrapDetectDescribeSurf.computeDescriptors (:116-128) for a caller-provided foundPoints list */
+int bhip_surf_describe_points(bhip_surf* s, int image, const double* xy_scale, int n, double* angle, uint8_t* white, double* desc);
+/* copy the integral image of image `image` of the last detect to host (width*height floats, dense) */
+int bhip_surf_fetch_integral(bhip_surf* s, int image, float* out);
+
+/* GIntegralImageOps.transform -> ImplIntegralImageOps.transform(GrayF32,GrayF32) (I:alg/transform/ii/impl/ImplIntegralImageOps.java:42-66) */
+int bhip_integral_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* out, int outStart, int outStride);
+/* IntegralImageFeatureIntensity.hessian(GrayF32,skip,size,GrayF32) (F:alg/feature/detect/intensity/IntegralImageFeatureIntensity.java:43-56);
+ * intensity is (width/skip) x (height/skip) */
+int bhip_hessian_f32(bhip_ctx* ctx, const float* ii, int iiStart, int iiStride, int width, int height, int skip, int size, float* intensity,
+					 int outStart, int outStride);
+/* NonMaxSuppression.process for the strict block extractor built by FactoryFeatureExtractor.nonmax(ConfigExtract(radius,threshold,border,true))
+ * (F:factory/feature/detect/extract/FactoryFeatureExtractor.java:63-102; F:alg/feature/detect/extract/NonMaxBlock.java:69-94).
+ * Writes up to cap (x,y) int16 pairs in block-raster order (the USE_CONCURRENT=false order); *n is the number found. */
+int bhip_nonmax_block_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, int radius, float threshold,
+						  int border, int16_t* xy, int cap, int* n);
+/* FastHessianFeatureDetector.detect(ii) (F:alg/feature/detect/interest/FastHessianFeatureDetector.java:156-188) on a host integral image */
+int bhip_fh_detect_f32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const float* ii, int iiStart, int iiStride, int width, int height, double* xy_scale,
+					   int cap, int* n);
+
+/* ---- association: FactoryAssociation.greedy(score,maxErr,backwards) -> AssociateDescription
+ *      (F:factory/feature/associate/FactoryAssociation.java:51-65; F:alg/feature/associate/AssociateGreedy.java:65-118;
+ *       F:abst/feature/associate/WrapAssociateGreedy.java:73-93).  pairs[i] = dst index or -1, fit[i] = AssociateGreedyBase.fitQuality. ---- */
+/* ScoreAssociateEuclideanSq_F64 (DescriptorDistance.euclideanSq, F:alg/descriptor/DescriptorDistance.java:55-64); sqrtScore!=0 gives
+ * ScoreAssociateEuclidean_F64 (:36-46) */
+int bhip_assoc_l2_f64(bhip_ctx* ctx, const double* src, int ns, const double* dst, int nd, int dof, double maxErr, int backwards, int sqrtScore,
+					  int* pairs, double* fit);
+/* ScoreAssociateHamming_B (DescriptorDistance.hamming, :196-220) on TupleDesc_B.data words */
+int bhip_assoc_hamming(bhip_ctx* ctx, const int32_t* src, int ns, const int32_t* dst, int nd, int words, double maxErr, int backwards, int* pairs,
+					   double* fit);
+/* device-resident forms (async on the ctx stream; outputs are device arrays) */
+int bhip_assoc_l2_dev(bhip_ctx* ctx, const double* dev_src, int ns, const double* dev_dst, int nd, int dof, double maxErr, int backwards,
+					  int sqrtScore, int* dev_pairs, double* dev_fit);
+int bhip_assoc_hamming_dev(bhip_ctx* ctx, const int32_t* dev_src, int ns, const int32_t* dev_dst, int nd, int words, double maxErr, int backwards,
+						   int* dev_pairs, double* dev_fit);
+/* batched device form: `count` independent (src,dst) problems in one launch sequence.  Problem p uses rows
+ * [srcOff[p], srcOff[p]+ns[p]) of dev_src and [dstOff[p], dstOff[p]+nd[p]) of dev_dst (host arrays of offsets/sizes);
+ * pairs/fit are written at the source row offsets. */
+int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double* dev_dst, int dof, int count, const long long* srcOff,
+							  const int* ns, const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit);
+
+/* sharded association: this rank owns source rows [srcBegin, srcBegin+nsLocal) of a global problem with nsGlobal rows and the
+ * whole destination set.  Phase 1 computes the local forward matches and, per destination column, the local column top-2
+ * (min1, argmin1 as GLOBAL source index, min2) into dev_colTop (nd records of {double min1; double min2; int idx1; int pad}).
+ * The caller all-gathers dev_colTop across ranks (RCCL, e.g. torch.distributed.all_gather_into_tensor) into nranks*nd records;
+ * phase 2 merges them and applies the strict column-minimum rule to the local rows. */
+int bhip_assoc_l2_shard_phase1(bhip_ctx* ctx, const double* dev_src, int nsLocal, int srcBegin, const double* dev_dst, int nd, int dof,
+							   double maxErr, int* dev_pairs, double* dev_fit, void* dev_colTop);
+int bhip_assoc_hamming_shard_phase1(bhip_ctx* ctx, const int32_t* dev_src, int nsLocal, int srcBegin, const int32_t* dev_dst, int nd, int words,
+									double maxErr, int* dev_pairs, double* dev_fit, void* dev_colTop);
+int bhip_assoc_shard_phase2(bhip_ctx* ctx, const void* dev_colTopAll, int nranks, int nd, int nsLocal, int srcBegin, int* dev_pairs,
+							double* dev_fit);
+int bhip_assoc_coltop_bytes(void); /* sizeof one column record */
+
+/* ---- boofcv-ip front end behind the BOverride* hooks ---- */
+/* BOverrideConvolveImage.horizontal/vertical (I:alg/filter/convolve/BOverrideConvolveImage.java:37-51) = ConvolveImageNoBorder
+ * (I:alg/filter/convolve/ConvolveImageNoBorder.java:53-77): border pixels of out are left untouched */
+int bhip_conv_h_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* in, int inStart, int inStride, int width,
+					int height, float* out, int outStart, int outStride);
+int bhip_conv_v_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* in, int inStart, int inStride, int width,
+					int height, float* out, int outStart, int outStride);
+/* BOverrideConvolveImageNormalized.horizontal/vertical (I:alg/filter/convolve/BOverrideConvolveImageNormalized.java:38-52) =
+ * ConvolveImageNormalized.horizontal/vertical (I:alg/filter/convolve/ConvolveImageNormalized.java:48-93) */
+int bhip_conv_norm_h_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* in, int inStart, int inStride,
+						 int width, int height, float* out, int outStart, int outStride);
+int bhip_conv_norm_v_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* in, int inStart, int inStride,
+						 int width, int height, float* out, int outStart, int outStride);
+/* BOverrideBlurImageOps.gaussian (I:alg/filter/blur/BOverrideBlurImageOps.java:38,48-49) = BlurImageOps.gaussian(GrayF32,out,sigma,radius,storage)
+ * (I:alg/filter/blur/BlurImageOps.java:406-425), sigmaX==sigmaY / radiusX==radiusY form */
+int bhip_gaussian_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, double sigma, int radius, float* out,
+					  int outStart, int outStride);
+/* GradientSobel.process(GrayF32,derivX,derivY,border) (I:alg/filter/derivative/GradientSobel.java:158-173);
+ * border: 0 = null (frame untouched), 1 = ImageBorderValue(0) */
+int bhip_sobel_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,
+				   int outStride, int border);
+/* GradientThree.process(GrayF32,...) -> GradientThree_Standard.process (I:alg/filter/derivative/impl/GradientThree_Standard.java:40-62) */
+int bhip_three_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,
+				   int outStride, int border);
+/* DescribePointBrief.process for n points on one image (F:alg/feature/describe/DescribePointBrief.java:73-89;
+ * F:alg/feature/describe/impl/ImplDescribeBinaryCompare_F32.java:47-101).  The definition (samplePoints[numPoints][2], compare[numPoints][2])
+ * is supplied by the caller: FactoryBriefDefinition.gaussian2 depends on java.util.Random + StrictMath and is generated on the Java side. */
+int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int width, int height, int radius, int numPoints,
+				   const int32_t* samplePoints, const int32_t* compare, const double* xy, int n, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOOFHIP_H */
