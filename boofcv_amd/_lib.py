@@ -47,6 +47,9 @@ SIGNATURES = {
     "bhip_ctx_synchronize": (_i, [_vp]),
     "bhip_last_error": (C.c_char_p, [_vp]),
     "bhip_version": (C.c_char_p, []),
+    "bhip_profile_enable": (_i, [_vp, _i]),
+    "bhip_profile_reset": (_i, [_vp]),
+    "bhip_profile_report": (_i, [_vp, C.c_char_p, _i]),
     "bhip_surf_create": (_i, [_vp, P(FhCfg), P(SurfCfg), P(OriCfg), _i, P(_vp)]),
     "bhip_surf_destroy": (_i, [_vp]),
     "bhip_surf_detect_f32": (_i, [_vp, P(_fp), _ip, _ip, _i, _i, _i]),
@@ -88,6 +91,29 @@ class BoofHipMissing(RuntimeError):
     pass
 
 
+def _preload_process_hip_runtime():
+    """One process must use ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's);
+    if libboofhip.so pulled in the system copy first and torch were imported later, the process would hold two runtimes and the
+    second one finds no GPU.  So when a torch wheel with a bundled runtime is installed, load that copy first (without importing
+    torch); libboofhip.so's NEEDED libamdhip64.so.7 then binds to it and device pointers / streams can be shared with torch."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libboofhip.so (no GPU needed for this step) and attach the signatures."""
     global _lib
@@ -95,6 +121,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise BoofHipMissing("%s not found: build it with `python -m boofcv_amd.build` (hipcc, gfx950). "
                                  "There is no CPU fallback." % LIB_PATH)
+        _preload_process_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here means the library and the header disagree

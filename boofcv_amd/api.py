@@ -58,6 +58,25 @@ class Context:
     def synchronize(self):
         _check(self, _lib.load().bhip_ctx_synchronize(self._h))
 
+    def profile(self, on=True):
+        """Bracket every kernel launch with HIP events on this context's stream."""
+        _check(self, _lib.load().bhip_profile_enable(self._h, 1 if on else 0))
+
+    def profileReset(self):
+        _check(self, _lib.load().bhip_profile_reset(self._h))
+
+    def profileReport(self):
+        """{tag: dict(launches, ms, bytes, flops)} accumulated since the last reset."""
+        L = _lib.load()
+        n = L.bhip_profile_report(self._h, None, 0)
+        buf = C.create_string_buffer(max(n, 1))
+        L.bhip_profile_report(self._h, buf, n)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            tag, launches, ms, b, f = line.split()
+            out[tag] = dict(launches=int(launches), ms=float(ms), bytes=float(b), flops=float(f))
+        return out
+
     def close(self):
         if self._h:
             _lib.load().bhip_ctx_destroy(self._h)

@@ -204,7 +204,11 @@ static int launchScan(bhip_ctx* ctx, const typename Scorer::elem* U, int nU, con
 	per = ((per + VT - 1) / VT) * VT;
 	dim3 grid((nU + 255) / 256, splits);
 	const size_t lds = (size_t)VT * len * sizeof(typename Scorer::elem);
-	hipLaunchKernelGGL((k_assoc_scan<Scorer, COLMODE>), grid, dim3(256), lds, ctx->stream, U, nU, V, nV, len, per, vBase, maxErr, sqrtScore, partial);
+	{
+		// one multiply-add pair per descriptor element per (u,v) pair: the N x M x len contraction of SURVEY 8d
+		ProfScope ps(ctx, COLMODE ? "k_assoc_scan_cols" : "k_assoc_scan_rows", 0, 2.0 * nU * (double)nV * len);
+		hipLaunchKernelGGL((k_assoc_scan<Scorer, COLMODE>), grid, dim3(256), lds, ctx->stream, U, nU, V, nV, len, per, vBase, maxErr, sqrtScore, partial);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

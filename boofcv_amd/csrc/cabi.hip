@@ -21,9 +21,16 @@ int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride,
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out);
 
+int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* dev_src, const double* dev_dst, int count, const long long* srcOff,
+								 const int* ns, const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit,
+								 int* usedMfma);
+void bhip_assoc_mfma_release(AssocMfmaWork& W);
+
 // per-context scratch that the stateless entry points reuse
 struct CtxScratch {
 	DevBuf a, b, c, d, e, work;
+	AssocMfmaWork mfma;
+	int assocExactOnly = -1;  // BHIP_ASSOC_EXACT=1 forces the exact VALU association kernels (parity cross-check)
 };
 static CtxScratch* scratchOf(bhip_ctx* ctx);
 
@@ -86,6 +93,7 @@ int bhip_ctx_destroy(bhip_ctx* c) {
 	(void)hipStreamSynchronize(ctx->stream);
 	CtxScratch& s = ctx->scratch;
 	s.a.release(); s.b.release(); s.c.release(); s.d.release(); s.e.release(); s.work.release();
+	bhip_assoc_mfma_release(s.mfma);
 	if (ctx->hostScratch) (void)hipHostFree(ctx->hostScratch);
 	if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -594,11 +602,36 @@ int bhip_fh_detect_f32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const float* ii, i
 // ---------------------------------------------------------------------------------------------------------------
 int bhip_assoc_coltop_bytes(void) { return bhip_assoc_coltop_size(); }
 
+static bool assocExactOnly(bhip_ctx* ctx) {
+	CtxScratch* sc = scratchOf(ctx);
+	if (sc->assocExactOnly < 0) {
+		const char* e = getenv("BHIP_ASSOC_EXACT");
+		sc->assocExactOnly = (e && e[0] == '1') ? 1 : 0;
+	}
+	return sc->assocExactOnly == 1;
+}
+
+static int assocL2Exact(bhip_ctx* ctx, const double* dev_src, int ns, const double* dev_dst, int nd, int dof, double maxErr, int backwards,
+						int sqrtScore, int* dev_pairs, double* dev_fit);
+
 int bhip_assoc_l2_dev(bhip_ctx* ctx, const double* dev_src, int ns, const double* dev_dst, int nd, int dof, double maxErr, int backwards,
 					  int sqrtScore, int* dev_pairs, double* dev_fit) {
 	CHECK_CTX(ctx);
 	if (ns < 0 || nd < 0 || dof <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
 	if (ns == 0) return BHIP_OK;
+	if (dof == 64 && !sqrtScore && nd > 0 && !assocExactOnly(ctx)) {
+		// matrix-core path (fp32 MFMA candidates + exact fp64 re-score); falls through on degenerate inputs
+		const long long zero = 0;
+		int used = 0;
+		BHIP_TRY(bhip_assoc_l2_mfma_batched(ctx, scratchOf(ctx)->mfma, dev_src, dev_dst, 1, &zero, &ns, &zero, &nd, maxErr, backwards, dev_pairs, dev_fit,
+											&used));
+		if (used) return BHIP_OK;
+	}
+	return assocL2Exact(ctx, dev_src, ns, dev_dst, nd, dof, maxErr, backwards, sqrtScore, dev_pairs, dev_fit);
+}
+
+static int assocL2Exact(bhip_ctx* ctx, const double* dev_src, int ns, const double* dev_dst, int nd, int dof, double maxErr, int backwards,
+						int sqrtScore, int* dev_pairs, double* dev_fit) {
 	CtxScratch* sc = scratchOf(ctx);
 	void* col = nullptr;
 	if (backwards && nd > 0) { BHIP_TRY(sc->d.reserve(ctx, (size_t)nd * bhip_assoc_coltop_size())); col = sc->d.p; }
@@ -623,9 +656,19 @@ int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double
 							  const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit) {
 	CHECK_CTX(ctx);
 	if (count < 0 || dof <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+	if (count == 0) return BHIP_OK;
+	if (!srcOff || !ns || !dstOff || !nd) return bhip_fail(ctx, BHIP_ERR_INVALID, "null problem table");
+	if (dof == 64 && !assocExactOnly(ctx)) {
+		int used = 0;
+		BHIP_TRY(bhip_assoc_l2_mfma_batched(ctx, scratchOf(ctx)->mfma, dev_src, dev_dst, count, srcOff, ns, dstOff, nd, maxErr, backwards, dev_pairs,
+											dev_fit, &used));
+		if (used) return BHIP_OK;
+	}
 	for (int p = 0; p < count; p++) {
-		BHIP_TRY(bhip_assoc_l2_dev(ctx, dev_src + srcOff[p] * dof, ns[p], dev_dst + dstOff[p] * dof, nd[p], dof, maxErr, backwards, 0, dev_pairs + srcOff[p],
-								   dev_fit + srcOff[p]));
+		if (ns[p] < 0 || nd[p] < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+		if (ns[p] == 0) continue;
+		BHIP_TRY(assocL2Exact(ctx, dev_src + srcOff[p] * dof, ns[p], dev_dst + dstOff[p] * dof, nd[p], dof, maxErr, backwards, 0, dev_pairs + srcOff[p],
+							  dev_fit + srcOff[p]));
 	}
 	return BHIP_OK;
 }

@@ -11,6 +11,14 @@
 
 #define BHIP_WAVE 64
 
+// one bracketed kernel launch (profiling mode only)
+struct ProfRecord {
+	const char* tag;
+	double algBytes;     // algorithmic HBM bytes of this launch, 0 when not an HBM-roofline kernel
+	double algFlops;     // algorithmic flops / integer ops of this launch, 0 when not a compute-roofline kernel
+	hipEvent_t start, stop;
+};
+
 struct bhip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -18,6 +26,18 @@ struct bhip_ctx {
 	std::string error;
 	// small pinned staging buffer for count read-backs
 	int* hostScratch = nullptr;
+	// optional per-kernel HIP-event timing on the ctx stream (bhip_profile_*)
+	bool profiling = false;
+	std::vector<ProfRecord> profRecords;
+	std::vector<hipEvent_t> eventPool;
+};
+
+// RAII bracket around one kernel launch: records a start/stop event pair on the ctx stream when profiling is on
+struct ProfScope {
+	bhip_ctx* ctx;
+	int idx = -1;
+	ProfScope(bhip_ctx* c, const char* tag, double algBytes = 0, double algFlops = 0);
+	~ProfScope();
 };
 
 static inline int bhip_fail(bhip_ctx* ctx, int code, const std::string& msg) {
@@ -52,6 +72,11 @@ struct DevBuf {
 	}
 	void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
 	template <class T> T* as() const { return (T*)p; }
+};
+
+// work buffers of the MFMA association path (assoc_mfma.hip)
+struct AssocMfmaWork {
+	DevBuf Fs, Fd, nrmS, nrmD, probs, blocks, keys, thr, best, args, cand, flags;
 };
 
 // ---------------- image view passed to kernels ----------------

@@ -107,7 +107,10 @@ int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* m
 	if (rw <= 0 || rh <= 0) return BHIP_OK;
 	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap};
 	dim3 grid((rw + 255) / 256, rh, batch);
-	hipLaunchKernelGGL(k_nms_scalespace, grid, dim3(256), 0, ctx->stream, P);
+	{
+		ProfScope ps(ctx, "k_nms_scalespace", 4.0 * p.w * p.h * batch);  // the mid level read once
+		hipLaunchKernelGGL(k_nms_scalespace, grid, dim3(256), 0, ctx->stream, P);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
@@ -146,7 +149,10 @@ __global__ __launch_bounds__(1024) void k_word_prefix(const unsigned int* __rest
 
 int bhip_launch_word_prefix(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, int batch, unsigned int* wordPrefix, int* totals) {
 	if (batch <= 0 || bitmapWords <= 0) return BHIP_OK;
-	hipLaunchKernelGGL(k_word_prefix, dim3(batch), dim3(1024), 0, ctx->stream, bitmap, bitmapWords, wordPrefix, totals);
+	{
+		ProfScope ps(ctx, "k_word_prefix", 8.0 * bitmapWords * batch);
+		hipLaunchKernelGGL(k_word_prefix, dim3(batch), dim3(1024), 0, ctx->stream, bitmap, bitmapWords, wordPrefix, totals);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
@@ -170,7 +176,10 @@ int bhip_launch_rank_scatter(bhip_ctx* ctx, const unsigned int* bitmap, int bitm
 							 const int* candCount, int cap, int batch, KeyPoint* sorted) {
 	if (batch <= 0 || cap <= 0) return BHIP_OK;
 	dim3 grid((cap + 255) / 256, batch);
-	hipLaunchKernelGGL(k_rank_scatter, grid, dim3(256), 0, ctx->stream, bitmap, bitmapWords, (const unsigned int*)wordPrefix, cand, candCount, cap, sorted);
+	{
+		ProfScope ps(ctx, "k_rank_scatter");
+		hipLaunchKernelGGL(k_rank_scatter, grid, dim3(256), 0, ctx->stream, bitmap, bitmapWords, (const unsigned int*)wordPrefix, cand, candCount, cap, sorted);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

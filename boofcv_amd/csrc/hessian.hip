@@ -139,7 +139,12 @@ int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlev
 	for (int i = 0; i < nlevels; i++) P.lv[i] = makeLevel(sizes[i], skip);
 	if (P.w <= 0 || P.h <= 0) return BHIP_OK;
 	dim3 grid((P.w + 255) / 256, P.h, batch * nlevels);
-	hipLaunchKernelGGL(k_hessian, grid, dim3(256), 0, ctx->stream, P);
+	{
+		// algorithmic bytes: the integral image once + every level's intensity written once
+		const double bytes = 4.0 * ii.width * ii.height * batch + 4.0 * nlevels * (double)P.w * P.h * batch;
+		ProfScope ps(ctx, skip == 1 ? "k_hessian_skip1" : "k_hessian_skipN", bytes);
+		hipLaunchKernelGGL(k_hessian, grid, dim3(256), 0, ctx->stream, P);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

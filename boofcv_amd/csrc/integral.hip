@@ -102,9 +102,16 @@ int bhip_launch_integral(bhip_ctx* ctx, ImgView in, ImgViewW out, int batch) {
 	const long long totalRows = (long long)in.height * batch;
 	const long long groups = (totalRows + TILE - 1) / TILE;
 	const unsigned blocks = (unsigned)((groups + 3) / 4);
-	hipLaunchKernelGGL(k_integral_rows, dim3(blocks), dim3(256), 0, ctx->stream, in, out, totalRows);
+	const double passBytes = 8.0 * in.width * in.height * batch;  // 4P read + 4P write per pass
+	{
+		ProfScope ps(ctx, "k_integral_rows", passBytes);
+		hipLaunchKernelGGL(k_integral_rows, dim3(blocks), dim3(256), 0, ctx->stream, in, out, totalRows);
+	}
 	dim3 grid((in.width + 255) / 256, batch);
-	hipLaunchKernelGGL(k_integral_cols, grid, dim3(256), 0, ctx->stream, out);
+	{
+		ProfScope ps(ctx, "k_integral_cols", passBytes);
+		hipLaunchKernelGGL(k_integral_cols, grid, dim3(256), 0, ctx->stream, out);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

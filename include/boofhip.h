@@ -90,6 +90,11 @@ int bhip_ctx_destroy(bhip_ctx* ctx);
 int bhip_ctx_synchronize(bhip_ctx* ctx);
 const char* bhip_last_error(bhip_ctx* ctx);
 const char* bhip_version(void);
+/* optional per-kernel timing with HIP events on the ctx stream (bench.py's live roofline numbers).  report writes one text line per
+ * kernel tag, "tag launches total_ms algorithmic_bytes algorithmic_flops", and returns the buffer size it needs. */
+int bhip_profile_enable(bhip_ctx* ctx, int on);
+int bhip_profile_reset(bhip_ctx* ctx);
+int bhip_profile_report(bhip_ctx* ctx, char* out, int cap);
 
 /* ---- detect + describe: FactoryDetectDescribe.surfStable / surfFast -> DetectDescribePoint<GrayF32,BrightFeature>
  *      (F:factory/feature/detdesc/FactoryDetectDescribe.java:118-135,209-226; F:abst/feature/detdesc/DetectDescribePoint.java:32-46;

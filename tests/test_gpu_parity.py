@@ -405,3 +405,88 @@ def test_brief_bit_exact(api, orc):
     assert np.array_equal(b.processAll(xy), orc.brief_describe(img, xy, 16, sp, cp))
     f = api.TupleDesc_B(512); b.process(80.5, 60.2, f)
     assert np.array_equal(f.data, orc.brief_describe(img, [[80.5, 60.2]], 16, sp, cp)[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------ MFMA association path
+def _assoc_exact_only(api, src, dst, maxErr, backwards):
+    """the exact fp64 VALU kernels, reached through a non-64 code path: sqrtScore=0 but forced by a private context flag"""
+    import os
+    os.environ["BHIP_ASSOC_EXACT"] = "1"
+    try:
+        ctx = api.Context(0)
+        a = api.FactoryAssociation.greedy(api.ScoreAssociateEuclideanSq_F64(), maxErr, backwards, ctx=ctx)
+        a.setSource(src); a.setDestination(dst); a.associate()
+        return a.getPairs().copy(), a.getFitQuality().copy()
+    finally:
+        del os.environ["BHIP_ASSOC_EXACT"]
+
+
+def test_mfma_association_config3_and_tie_stress(api, orc):
+    """BASELINE config 3: two 4096-key-point SURF-64 sets; B = A permuted + N(0,0.05) for 3072 rows, fresh for 1024."""
+    rng = np.random.default_rng(1)
+    A = _surf_like(rng, 4096)
+    perm = rng.permutation(4096)
+    Bm = A[perm].copy()
+    Bm[:3072] += np.random.default_rng(2).normal(scale=0.05, size=(3072, 64))
+    Bm[3072:] = _surf_like(np.random.default_rng(3), 1024)
+    Bm /= np.linalg.norm(Bm, axis=1, keepdims=True)
+    a = _greedy(api, api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True, A, Bm)
+    p, f = orc.associate_l2(A, Bm, api.Double_MAX_VALUE, True, threads=8)
+    assert np.array_equal(a.getPairs(), p) and np.array_equal(a.getFitQuality(), f)
+    assert (p >= 0).sum() > 2500
+    pe, fe = _assoc_exact_only(api, A, Bm, api.Double_MAX_VALUE, True)
+    assert np.array_equal(pe, p) and np.array_equal(fe, f)  # exact VALU path == MFMA path == oracle
+    # tie stress: exact duplicates on both sides, near-duplicates one ulp apart
+    A2 = A[:1500].copy(); A2[100:200] = A2[0:100]
+    B2 = np.concatenate([A2[::-1], A2[:300]]); B2[5] = np.nextafter(B2[5], 2.0)
+    for backwards in (False, True):
+        for maxErr in (api.Double_MAX_VALUE, 1e-3):
+            a = _greedy(api, api.ScoreAssociateEuclideanSq_F64(), maxErr, backwards, A2, B2)
+            p, f = orc.associate_l2(A2, B2, maxErr, backwards, threads=8)
+            assert np.array_equal(a.getPairs(), p) and np.array_equal(a.getFitQuality(), f)
+
+
+def test_mfma_association_degenerate_inputs_fall_back(api, orc):
+    z = np.zeros((300, 64)); one = np.tile(_surf_like(np.random.default_rng(0), 1), (260, 1))
+    for src, dst in [(z, z), (one, one), (z, one)]:  # every pair is a candidate: list overflow -> exact path
+        a = _greedy(api, api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True, src, dst)
+        p, f = orc.associate_l2(src, dst, api.Double_MAX_VALUE, True)
+        assert np.array_equal(a.getPairs(), p) and np.array_equal(a.getFitQuality(), f)
+    big = _surf_like(np.random.default_rng(4), 100) * 1e200  # norms overflow fp32: exact path
+    a = _greedy(api, api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True, big, big[::-1].copy())
+    p, f = orc.associate_l2(big, big[::-1].copy(), api.Double_MAX_VALUE, True)
+    assert np.array_equal(a.getPairs(), p) and np.array_equal(a.getFitQuality(), f)
+    unnorm = np.random.default_rng(5).normal(size=(500, 64)) * np.random.default_rng(6).uniform(0.01, 100, size=(500, 1))  # wildly different norms
+    a = _greedy(api, api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True, unnorm, unnorm[::-1] * 1.0000001)
+    p, f = orc.associate_l2(unnorm, unnorm[::-1] * 1.0000001, api.Double_MAX_VALUE, True)
+    assert np.array_equal(a.getPairs(), p) and np.array_equal(a.getFitQuality(), f)
+
+
+def test_batched_device_association(api, orc):
+    """bhip_assoc_l2_dev_batched: several (src,dst) problems that share one descriptor buffer, as bench.py uses it."""
+    import ctypes as C
+    import torch
+    from boofcv_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(9)
+    sizes = [700, 1, 350, 64, 129]
+    sets = [_surf_like(rng, n) for n in sizes]
+    sets[2][:300] = sets[0][:300] + rng.normal(scale=0.02, size=(300, 64))
+    allrows = np.concatenate(sets)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    dev = torch.from_numpy(allrows).cuda()
+    n = len(sizes)
+    src_off = np.ascontiguousarray(starts[:n]); dst_idx = (np.arange(n) + 2) % n
+    dst_off = np.ascontiguousarray(starts[dst_idx]); ns = np.array(sizes, np.int32); nd = np.ascontiguousarray(ns[dst_idx])
+    pairs = torch.full((len(allrows),), -7, dtype=torch.int32, device="cuda"); fit = torch.zeros(len(allrows), dtype=torch.float64, device="cuda")
+    ctx = api.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    LL, I = C.POINTER(C.c_longlong), C.POINTER(C.c_int)
+    st = L.bhip_assoc_l2_dev_batched(ctx._h, C.c_void_p(dev.data_ptr()), C.c_void_p(dev.data_ptr()), 64, n, src_off.ctypes.data_as(LL), ns.ctypes.data_as(I),
+                                     dst_off.ctypes.data_as(LL), nd.ctypes.data_as(I), api.Double_MAX_VALUE, 1, C.c_void_p(pairs.data_ptr()),
+                                     C.c_void_p(fit.data_ptr()))
+    assert st == 0, L.bhip_last_error(ctx._h)
+    torch.cuda.synchronize()
+    pairs, fit = pairs.cpu().numpy(), fit.cpu().numpy()
+    for k in range(n):
+        p, f = orc.associate_l2(sets[k], sets[dst_idx[k]], api.Double_MAX_VALUE, True)
+        assert np.array_equal(pairs[starts[k]:starts[k + 1]], p) and np.array_equal(fit[starts[k]:starts[k + 1]], f), k
