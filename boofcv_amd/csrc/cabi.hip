@@ -263,7 +263,7 @@ static int buildTables(bhip_surf* s) {
 	const bhip_surf_cfg& c = s->sd;
 	const bhip_ori_cfg& o = s->ori;
 	if (c.widthLargeGrid < 1 || c.widthSubRegion < 1 || c.widthSample < 1 || c.overLap < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad SURF config");
-	if (o.radius < 1 || o.radius > 16) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation radius out of range");
+	if (o.radius < 1 || o.radius > 10) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation radius out of range (1..10 on the GPU)");
 	std::vector<double> all;
 	auto push = [&](const std::vector<double>& v) { size_t off = all.size(); all.insert(all.end(), v.begin(), v.end()); return off; };
 	t.oriStable = s->stable;

@@ -14,12 +14,15 @@
 // Arithmetic: gradients are fp32 box differences of the integral image (exact order kept), everything after that is fp64 in the
 // reference's order with no FMA contraction.  The reference picks an unguarded sampler when SurfDescribeOps.isInside says the whole
 // region is inside the image; the guarded sampler returns the same values there, so the device always samples guarded (never reads
-// outside the image) and the isInside test disappears.  The 289 orientation angles are ordered by (angle, sample index): the
+// outside the image) and the isInside test disappears.  The orientation angles are ordered by (angle, sample index): the
 // reference's ddogleg QuickSort_F64 is unstable and its tie order is not pinned by any reference test (SURVEY hard part 5).
 //
-// Work split inside a wave: samples are spread over the 64 lanes and staged in LDS; the order-dependent fp64 reductions
-// (sliding-window sweep, 81-term sub-region sums, L2 norm) each run on one lane per independent chain so they round exactly as
-// the sequential Java loops do.
+// Structure: the kernel is latency bound (long chains of dependent LDS / L2 reads at 3-4 waves per SIMD), so every phase is written
+// to keep many independent loads in flight:
+//   * gathers are branch-free (out-of-bounds samples read a safe address and are zeroed afterwards) and issued in unrolled batches;
+//   * the merge sort and the window searches advance all of a lane's binary searches in lock step;
+//   * the 81-term sub-region sums keep the reference's sequential fp64 order per output but fetch a whole row of samples and
+//     weights per wait.
 #include "common.h"
 
 struct DescParams {
@@ -36,8 +39,12 @@ struct DescParams {
 	double* desc;             // [total][dof]
 	uint8_t* white;           // [total]
 	int ldsPerWave;           // bytes
-	int gridW;                // descriptor sample grid width
+	unsigned long long* stamps; // diagnostic build only: [total][8] cycle stamps
+	int serialOnly;           // BHIP_DESCRIBE_SERIAL=1: always run the reference's serial window sweep (cross-check of the parallel form)
 };
+
+#define ORI_EPL_MAX 8     // orientation samples per lane (n <= 512, i.e. radius <= 10)
+#define DESC_ROW_MAX 16   // samples per sub-region row (widthSubRegion + 2*overLap)
 
 // ---- sparse gradient (SparseIntegralGradient_NoBorder_F32) ----
 __device__ __forceinline__ int gradRadius(double width) {
@@ -45,13 +52,28 @@ __device__ __forceinline__ int gradRadius(double width) {
 	if (r <= 0) r = 1;
 	return r;
 }
-__device__ __forceinline__ bool gradInBounds(int x, int y, int r, int W, int H) { return x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < W && y + r < H; }
-__device__ __forceinline__ void gradCompute(const float* __restrict__ d, int stride, int x, int y, int r, float& gx, float& gy) {
-	const int w = 2 * r + 1;
-	const long long s1 = (long long)(y - r - 1) * stride + (x - r - 1);
-	const long long s2 = s1 + (long long)r * stride;
-	const long long s3 = s2 + stride;
-	const long long s4 = s3 + (long long)r * stride;
+// branch-free guarded sample: taps are always fetched (from (safe, safe) when the kernel leaves the image), the result is zeroed
+// afterwards.  `anyInside` is false when the image is smaller than the kernel (then every sample is zero and nothing is read).
+struct GradGeom {
+	int r, w, stride, W, H;
+	int safe;        // an in-bounds centre coordinate: r + 1
+	bool anyInside;  // 2r + 2 <= min(W, H)
+};
+__device__ __forceinline__ GradGeom makeGeom(int r, int stride, int W, int H) {
+	GradGeom g;
+	g.r = r; g.w = 2 * r + 1; g.stride = stride; g.W = W; g.H = H; g.safe = r + 1;
+	g.anyInside = (2 * r + 2 <= W) && (2 * r + 2 <= H);
+	return g;
+}
+__device__ __forceinline__ void gradSample(const float* __restrict__ d, const GradGeom& G, int x, int y, float& gx, float& gy) {
+	const int r = G.r;
+	const bool inb = x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < G.W && y + r < G.H;
+	const int xs = inb ? x : G.safe, ys = inb ? y : G.safe;
+	const long long s1 = (long long)(ys - r - 1) * G.stride + (xs - r - 1);
+	const long long s2 = s1 + (long long)r * G.stride;
+	const long long s3 = s2 + G.stride;
+	const long long s4 = s3 + (long long)r * G.stride;
+	const int w = G.w;
 	const float p0 = d[s1], p1 = d[s1 + r], p2 = d[s1 + r + 1], p3 = d[s1 + w];
 	const float p11 = d[s2], p4 = d[s2 + w];
 	const float p10 = d[s3], p5 = d[s3 + w];
@@ -60,12 +82,8 @@ __device__ __forceinline__ void gradCompute(const float* __restrict__ d, int str
 	const float right = p6 - p7 - p3 + p2;
 	const float top = p4 - p11 - p3 + p0;
 	const float bottom = p6 - p9 - p5 + p10;
-	gx = right - left;
-	gy = bottom - top;
-}
-__device__ __forceinline__ void gradSafe(const float* __restrict__ d, int stride, int W, int H, int x, int y, int r, float& gx, float& gy) {
-	if (gradInBounds(x, y, r, W, H)) gradCompute(d, stride, x, y, r, gx, gy);
-	else { gx = 0.0f; gy = 0.0f; }
+	gx = inb ? right - left : 0.0f;
+	gy = inb ? bottom - top : 0.0f;
 }
 
 // ---- clamped box sum (ImplIntegralImageOps.block_zero) for the Laplacian sign ----
@@ -93,6 +111,318 @@ __device__ __forceinline__ void waveSync() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stable merge sort of the n (angle, index) pairs in LDS: runs of EPL consecutive elements per lane (insertion sort in registers),
+// then log2 rounds in which every element finds its slot by a binary search in the sibling run.  All of a lane's searches advance
+// in lock step so each round costs ~log2(L) LDS round trips instead of EPL times that.  On return keyA holds the sorted angles
+// and dX, dY are permuted into the same order.
+template <int EPLT>
+__device__ __forceinline__ void sortSamplesByAngle(double* dX, double* dY, double* keyA, double* keyB, unsigned short* idxA, unsigned short* idxB, int n,
+													int lane) {
+	const int EPL = (n + 63) >> 6;   // <= EPLT
+	const int p0 = lane * EPL;
+	const int cnt = max(0, min(EPL, n - p0));
+	{
+		double k[EPLT];
+		unsigned short id[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			k[e] = e < cnt ? keyA[p0 + e] : 0.0;
+			id[e] = (unsigned short)(p0 + e);
+		}
+#pragma unroll
+		for (int e = 1; e < EPLT; e++) {
+#pragma unroll
+			for (int f = e; f >= 1; f--) {
+				if (f < cnt && k[f - 1] > k[f]) {
+					const double tk = k[f]; k[f] = k[f - 1]; k[f - 1] = tk;
+					const unsigned short ti = id[f]; id[f] = id[f - 1]; id[f - 1] = ti;
+				}
+			}
+		}
+		waveSync();
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (e < cnt) { keyA[p0 + e] = k[e]; idxA[p0 + e] = id[e]; }
+	}
+	waveSync();
+	double* srcK = keyA; double* dstK = keyB;
+	unsigned short* srcI = idxA; unsigned short* dstI = idxB;
+	for (int L = EPL; L < n; L <<= 1) {
+		double key[EPLT];
+		int lo[EPLT], hi[EPLT], base[EPLT];
+		bool right[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int p = p0 + e;
+			const int q = p / L;
+			const int runStart = q * L;
+			right[e] = q & 1;
+			const int sibStart = right[e] ? runStart - L : runStart + L;
+			lo[e] = min(sibStart, n);
+			hi[e] = min(sibStart + L, n);
+			key[e] = e < cnt ? srcK[p] : 0.0;
+			// destination = pairBase + (p - runStart) + (#sibling elements ordered before key); lo ends as sibStart + that count
+			base[e] = (right[e] ? sibStart : runStart) + (p - runStart) - min(sibStart, n);
+			if (e >= cnt) hi[e] = lo[e];
+		}
+		// every step halves [lo,hi): ceil(log2(L+1)) steps settle all searches
+		for (int span = L; span > 0; span >>= 1) {
+			double v[EPLT];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				const int mid = (lo[e] + hi[e]) >> 1;
+				v[e] = lo[e] < hi[e] ? srcK[mid] : 0.0;
+			}
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				if (lo[e] < hi[e]) {
+					const int mid = (lo[e] + hi[e]) >> 1;
+					// left-run elements go before equal right-run elements (stable): strictly-less for left, less-or-equal for right
+					const bool before = right[e] ? (v[e] <= key[e]) : (v[e] < key[e]);
+					if (before) lo[e] = mid + 1; else hi[e] = mid;
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			if (e < cnt) {
+				const int dst = base[e] + lo[e];
+				dstK[dst] = key[e];
+				dstI[dst] = srcI[p0 + e];
+			}
+		}
+		waveSync();
+		double* tk = srcK; srcK = dstK; dstK = tk;
+		unsigned short* ti = srcI; srcI = dstI; dstI = ti;
+	}
+	{
+		double x[EPLT], y[EPLT], a[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			if (e < cnt) { const int i = srcI[p0 + e]; x[e] = dX[i]; y[e] = dY[i]; a[e] = srcK[p0 + e]; }
+		}
+		waveSync();
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			if (e < cnt) { dX[p0 + e] = x[e]; dY[p0 + e] = y[e]; keyA[p0 + e] = a[e]; }
+		}
+	}
+	waveSync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sliding-window orientation, wave-parallel form of ImplOrientationSlidingWindowIntegral.estimateAngle (:139-188).
+//
+// The reference sorts the n angles and sweeps two pointers: for every start a the window grows while
+// UtilAngle.dist(angle[a], angle[end]) <= windowSize, keeping running sums that gain the element at `end` and later lose the
+// element at `start`; after every gain it tests |sum|^2 > best.  Which elements are in the window at each test depends only on
+// the sorted angles, so the candidate windows are enumerated in parallel:
+//   c(a)  = number of consecutive successors of a inside its window (binary search: the predicate is monotone on the leading side)
+//   E(a)  = max(E(a-1), a + c(a) + 1), E(-1) = 1          position of `end` after start a (a max-scan over the wave)
+//   the test made right after element E joins belongs to start a(E) = min{a : E(a) > E} and sees the sorted elements a(E)..E
+// Every test the reference makes is made here on the same set of elements; the window sum is taken as a difference of prefix sums
+// over the sorted samples instead of the reference's running add/subtract chain, so the two differ only by fp64 rounding of the
+// sums (~1e-15 relative), far inside the 1e-5 descriptor bar.  The first maximum in sweep order wins, as in the reference.
+// The full-circle regime (some window wraps all the way round: ramps, flat patches) is detected and left to the serial code.
+// Returns false when the caller must run the serial sweep (the arrays are then still the sorted samples).
+template <int EPLT>
+__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, int* Esched, int n, double window, int lane, double& bestX,
+												   double& bestY) {
+	const int EPL = (n + 63) >> 6;   // <= EPLT
+	const int p0 = lane * EPL;
+	const int cnt = max(0, min(EPL, n - p0));
+	bool abnormal = false;
+	int valE[EPLT];   // a + c(a) + 1
+	int runMax = 0;
+	{
+		// c(a): largest t with "successor t is on the leading side and inside the window"; all searches of this lane in lock step
+		double ta[EPLT];
+		int lo[EPLT], hi[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			ta[e] = e < cnt ? sA[p0 + e] : 0.0;
+			lo[e] = 0;
+			hi[e] = e < cnt ? n : 1;
+		}
+		for (int span = n; span > 1; span = (span + 1) >> 1) {
+			double tk[EPLT];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				const int mid = (lo[e] + hi[e]) >> 1;
+				const int kabs = p0 + e + mid;
+				const int k = kabs >= n ? kabs - n : kabs;
+				tk[e] = (hi[e] - lo[e] > 1) ? sA[k] : 0.0;
+			}
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				if (hi[e] - lo[e] > 1) {
+					const int mid = (lo[e] + hi[e]) >> 1;
+					const int kabs = p0 + e + mid;
+					const double fo = (tk[e] - ta[e]) + (kabs >= n ? 2.0 * M_PI : 0.0);
+					const bool ok = fo < M_PI && angleDist(ta[e], tk[e]) <= window;
+					if (ok) lo[e] = mid; else hi[e] = mid;
+				}
+			}
+		}
+		double nxt[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int kabs = p0 + e + lo[e] + 1;
+			const int k = kabs >= n ? kabs - n : kabs;
+			nxt[e] = (e < cnt && lo[e] < n - 1) ? sA[k] : 0.0;
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			valE[e] = 0;
+			if (e < cnt) {
+				const int c = lo[e];
+				if (c >= n - 1) abnormal = true;
+				// the reference stops at the first successor that fails its test; make sure that really is successor c+1
+				else if (angleDist(ta[e], nxt[e]) <= window) abnormal = true;
+				valE[e] = p0 + e + c + 1;
+				runMax = max(runMax, valE[e]);
+			}
+		}
+	}
+	// inclusive max-scan of the per-lane maxima, then the exclusive value for this lane (E(-1) = 1)
+	int scan = runMax;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(scan, o, 64);
+		if (lane >= o) scan = max(scan, t);
+	}
+	int prevE = __shfl_up(scan, 1, 64);
+	if (lane == 0) prevE = 1;
+	prevE = max(prevE, 1);
+	// ---- validate the schedule (full-circle regime -> serial code), before the samples are overwritten by their prefix sums
+	int lastE = 1;
+	{
+		int pe = prevE;
+		double chk[EPLT];
+		bool need[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			need[e] = false;
+			chk[e] = 0.0;
+			if (e < cnt) {
+				const int a = p0 + e;
+				const int Ea = max(pe, valE[e]);
+				if (pe > valE[e] - 1 && pe > a && pe < a + n) {
+					// `end` is already beyond this start's leading window: the reference tests it once and it must fail
+					const int k = pe >= n ? pe - n : pe;
+					need[e] = true;
+					chk[e] = sA[k];
+				}
+				if (Ea >= a + n) abnormal = true;
+				pe = Ea;
+				Esched[a] = Ea;
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (need[e] && angleDist(sA[p0 + e], chk[e]) <= window) abnormal = true;
+		lastE = pe;
+	}
+	if (__any(abnormal)) return false;
+	lastE = __shfl(lastE, (n - 1) / EPL, 64);  // E(n-1): one past the last end position that is ever tested
+	// ---- inclusive prefix sums of (dX, dY) in sorted order, in place: window sum(a..E) = I[E] - I[a-1]
+	{
+		double lx[EPLT], ly[EPLT], vx[EPLT], vy[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			vx[e] = e < cnt ? dX[p0 + e] : 0.0;
+			vy[e] = e < cnt ? dY[p0 + e] : 0.0;
+		}
+		double tx = 0, ty = 0;
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			tx += vx[e]; ty += vy[e];
+			lx[e] = tx; ly[e] = ty;
+		}
+		double ox = tx, oy = ty;   // inclusive scan of the lane totals
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const double ux = __shfl_up(ox, o, 64), uy = __shfl_up(oy, o, 64);
+			if (lane >= o) { ox += ux; oy += uy; }
+		}
+		ox -= tx; oy -= ty;        // exclusive
+		waveSync();
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (e < cnt) { dX[p0 + e] = ox + lx[e]; dY[p0 + e] = oy + ly[e]; }
+	}
+	waveSync();
+	const double totX = dX[n - 1], totY = dY[n - 1];
+	// ---- candidate windows, one per end position E in [1, E(n-1)), EPLT of them per lane at a time
+	double bMag = -1.0, bX = 0, bY = 0;
+	int bPos = 0x7fffffff;
+	if (lane == 0) { bX = dX[0]; bY = dY[0]; bMag = bX * bX + bY * bY; bPos = 0; }
+	for (int E0 = 1 + lane * EPLT; E0 < lastE; E0 += 64 * EPLT) {
+		int lo[EPLT], hi[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int E = E0 + e;
+			lo[e] = 0;
+			hi[e] = E < lastE ? min(E, n - 1) : 0;   // owner is in [0, min(E, n-1)]: E(a) > a always
+		}
+		for (int span = n; span > 0; span >>= 1) {
+			int ev[EPLT];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) ev[e] = lo[e] < hi[e] ? Esched[(lo[e] + hi[e]) >> 1] : 0;
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				if (lo[e] < hi[e]) {
+					const int mid = (lo[e] + hi[e]) >> 1;
+					if (ev[e] > E0 + e) hi[e] = mid; else lo[e] = mid + 1;
+				}
+			}
+		}
+		double ax[EPLT], ay[EPLT], ex[EPLT], ey[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int E = E0 + e;
+			const bool on = E < lastE;
+			const int a = lo[e];
+			const int ke = E >= n ? E - n : E;
+			ax[e] = (on && a > 0) ? dX[a - 1] : 0.0;
+			ay[e] = (on && a > 0) ? dY[a - 1] : 0.0;
+			ex[e] = on ? dX[ke] : 0.0;
+			ey[e] = on ? dY[ke] : 0.0;
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int E = E0 + e;
+			if (E < lastE) {
+				double sx, sy;
+				if (E < n) { sx = ex[e] - ax[e]; sy = ey[e] - ay[e]; }
+				else { sx = (totX - ax[e]) + ex[e]; sy = (totY - ay[e]) + ey[e]; }
+				const double mag = sx * sx + sy * sy;
+				if (mag > bMag) { bMag = mag; bX = sx; bY = sy; bPos = E; }   // E increases within a lane: strict > keeps the first
+			}
+		}
+	}
+	// ---- first maximum in sweep order across the wave: max magnitude, then the smallest position among the lanes that hold it
+	double m = bMag;
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+	int pos = (bMag == m) ? bPos : 0x7fffffff;
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) pos = min(pos, __shfl_xor(pos, o, 64));
+	const unsigned long long owner = __ballot(bMag == m && bPos == pos);
+	const int src = __ffsll((long long)owner) - 1;
+	bestX = __shfl(bX, src, 64);
+	bestY = __shfl(bY, src, 64);
+	return true;
+}
+
+// STAMP = true is a diagnostic build (BHIP_DESCRIBE_STAMPS): lane 0 of every wave records the cycle counter at the phase boundaries
+// into a buffer nothing else reads; never used for results or for quoted run times.
+#define DSTAMP(i) do { if (STAMP && lane == 0) P.stamps[g * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+
+// EPLT = orientation samples per lane = ceil(n / 64), TWT = samples per sub-region row: compile-time for the common configurations so
+// the unrolled batches carry no dead slots (the kernel is issue bound); <8,16> is the generic instantiation.
+template <bool STAMP, int EPLT, int TWT>
 __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ldsAll[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -119,6 +449,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const SurfTables& T = P.t;
 
+	DSTAMP(0);
 	// ------------------------------------------------------------------ orientation
 	double angle;
 	if (P.anglesIn) {
@@ -126,7 +457,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	} else {
 		const double radius = kp.scale * 2.0;                 // BoofDefaults.SURF_SCALE_TO_RADIUS
 		const double oscale = radius * T.oriRadiusToScale;    // setObjectRadius
-		const int r = gradRadius(oscale * T.oriKernelWidth);
+		const GradGeom G = makeGeom(gradRadius(oscale * T.oriKernelWidth), stride, W, H);
 		const double period = oscale * T.oriPeriod;
 		double tl_x = kp.x - T.oriRadius * period;
 		double tl_y = kp.y - T.oriRadius * period;
@@ -136,82 +467,91 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		double* dX = (double*)lds;
 		double* dY = dX + n;
 		double* ang = dY + n;
-		int* order = (int*)(ang + n);
-		for (int idx = lane; idx < n; idx += 64) {
-			const int sy = idx / sw, sx = idx - sy * sw;
-			const int xx = (int)(tl_x + sx * period);
-			const int yy = (int)(tl_y + sy * period);
-			float gx, gy;
-			gradSafe(d, stride, W, H, xx, yy, r, gx, gy);
-			double dx = (double)gx, dy = (double)gy;
-			if (T.oriStable) {
-				if (T.oriHasWeights) {
-					const double w = T.oriWeights[idx];
-					dx *= w;
-					dy *= w;
+		double* keyB = ang + n;
+		{
+			// all of this lane's samples: taps first (independent loads in flight together), then the fp64 tail
+			float gx[EPLT], gy[EPLT];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				const int idx = lane + 64 * e;
+				gx[e] = 0.0f; gy[e] = 0.0f;
+				if (idx < n && G.anyInside) {
+					const int sy = idx / sw, sx = idx - sy * sw;
+					const int xx = (int)(tl_x + sx * period);
+					const int yy = (int)(tl_y + sy * period);
+					gradSample(d, G, xx, yy, gx[e], gy[e]);
 				}
-				dX[idx] = dx;
-				dY[idx] = dy;
-				ang[idx] = atan2(dy, dx);
-			} else {
-				// average variant accumulates w*gx (or gx) in row-major order; stage the addends
-				if (T.oriHasWeights) {
-					const double w = T.oriWeights[idx];
-					dX[idx] = w * dx;
-					dY[idx] = w * dy;
-				} else {
-					dX[idx] = dx;
-					dY[idx] = dy;
+			}
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				const int idx = lane + 64 * e;
+				if (idx < n) {
+					double dx = (double)gx[e], dy = (double)gy[e];
+					if (T.oriStable) {
+						if (T.oriHasWeights) {
+							const double w = T.oriWeights[idx];
+							dx *= w;
+							dy *= w;
+						}
+						dX[idx] = dx;
+						dY[idx] = dy;
+						ang[idx] = atan2(dy, dx);
+					} else {
+						// average variant accumulates w*gx (or gx) in row-major order; stage the addends
+						if (T.oriHasWeights) {
+							const double w = T.oriWeights[idx];
+							dX[idx] = w * dx;
+							dY[idx] = w * dy;
+						} else {
+							dX[idx] = dx;
+							dY[idx] = dy;
+						}
+					}
 				}
 			}
 		}
 		waveSync();
+		DSTAMP(1);
 		if (T.oriStable) {
-			// arg-sort ascending by (angle, index): rank = number of elements ordered before mine
-			for (int idx = lane; idx < n; idx += 64) {
-				const double a = ang[idx];
-				int rank = 0;
-				for (int j = 0; j < n; j++) {
-					const double b = ang[j];
-					rank += (b < a || (b == a && j < idx)) ? 1 : 0;
-				}
-				order[rank] = idx;
-			}
-			waveSync();
+			unsigned short* idxA = (unsigned short*)(keyB + n);
+			unsigned short* idxB = idxA + n;
 			double bestX = 0, bestY = 0;
-			if (lane == 0) {
-				// estimateAngle(): sequential two-pointer sweep, exactly as written in the reference
-				const int total = n;
-				int start = 0, end = 1;
-				int startIndex = order[start];
-				int endIndex = order[end];
-				double sumX = dX[startIndex], sumY = dY[startIndex];
-				double best = sumX * sumX + sumY * sumY;
-				bestX = sumX;
-				bestY = sumY;
-				double endAngle = ang[endIndex];
-				const double window = T.oriWindow;
-				while (start != total) {
-					startIndex = order[start];
-					const double startAngle = ang[startIndex];
-					while (angleDist(startAngle, endAngle) <= window) {
-						sumX += dX[endIndex];
-						sumY += dY[endIndex];
-						const double mag = sumX * sumX + sumY * sumY;
-						if (mag > best) { best = mag; bestX = sumX; bestY = sumY; }
-						end++;
-						if (end >= total) end = 0;
-						endIndex = order[end];
-						endAngle = ang[endIndex];
-						if (endIndex == startIndex) break;
+			bool needSerial = true;
+			sortSamplesByAngle<EPLT>(dX, dY, ang, keyB, idxA, idxB, n, lane);   // n <= 64 * EPLT is enforced on the host
+			DSTAMP(2);
+			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, (int*)keyB, n, T.oriWindow, lane, bestX, bestY);
+			if (needSerial) {
+				// estimateAngle() exactly as written in the reference, on the arrays already in sorted order (order[k] == k).
+				// Reached for the full-circle regime (all gradients within one window of each other: ramps, flat patches).
+				if (lane == 0) {
+					const int total = n;
+					int start = 0, end = 1;
+					double sumX = dX[0], sumY = dY[0];
+					double best = sumX * sumX + sumY * sumY;
+					bestX = sumX;
+					bestY = sumY;
+					double endAngle = ang[end];
+					const double window = T.oriWindow;
+					while (start != total) {
+						const double startAngle = ang[start];
+						while (angleDist(startAngle, endAngle) <= window) {
+							sumX += dX[end];
+							sumY += dY[end];
+							const double mag = sumX * sumX + sumY * sumY;
+							if (mag > best) { best = mag; bestX = sumX; bestY = sumY; }
+							end++;
+							if (end >= total) end = 0;
+							endAngle = ang[end];
+							if (end == start) break;
+						}
+						sumX -= dX[start];
+						sumY -= dY[start];
+						start++;
 					}
-					sumX -= dX[startIndex];
-					sumY -= dY[startIndex];
-					start++;
 				}
+				bestX = __shfl(bestX, 0, 64);
+				bestY = __shfl(bestY, 0, 64);
 			}
-			bestX = __shfl(bestX, 0, 64);
-			bestY = __shfl(bestY, 0, 64);
 			angle = atan2(bestY, bestX);
 		} else {
 			double Dx = 0, Dy = 0;
@@ -224,13 +564,14 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		}
 		waveSync();
 	}
+	DSTAMP(3);
 	if (lane == 0 && P.angles) P.angles[g] = angle;
 	if (!P.desc) return;
 
 	// ------------------------------------------------------------------ descriptor
 	const double c = cos(angle), s = sin(angle);
 	const double scale = kp.scale;
-	const int r = gradRadius(T.widthSample * scale);
+	const GradGeom G = makeGeom(gradRadius(T.widthSample * scale), stride, W, H);
 	const int regionSize = T.widthLargeGrid * T.widthSubRegion;
 	const int regionR = regionSize / 2;
 	const int overLap = T.stable ? T.overLap : 0;
@@ -240,48 +581,85 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	float* sY = sX + nsamp;
 	double* feat = (double*)(sY + nsamp + (nsamp & 1));  // keep 8-byte alignment
 	{
+		// sample grid in 8x8 blocks: the 64 lanes of one pass cover a compact (8 scale)^2 patch of the image, so a wave-level gather
+		// touches a few dozen cache lines instead of up to 64.  The LDS layout stays [iy][ix].
 		const double c_x = kp.x + 0.5, c_y = kp.y + 0.5;
-		for (int idx = lane; idx < nsamp; idx += 64) {
-			const int iy = idx / gridW, ix = idx - iy * gridW;
-			const int rY = iy - regionR - overLap, rX = ix - regionR - overLap;
-			const double regionY = rY * scale;
-			const double regionX = rX * scale;
-			const int pixelX = (int)(c_x + c * regionX - s * regionY);
-			const int pixelY = (int)(c_y + s * regionX + c * regionY);
-			float gx, gy;
-			gradSafe(d, stride, W, H, pixelX, pixelY, r, gx, gy);
-			sX[idx] = gx;
-			sY[idx] = gy;
+		const int blocksPerSide = (gridW + 7) >> 3;
+		const int nblocks = blocksPerSide * blocksPerSide;
+		const int ly = lane >> 3, lx = lane & 7;
+		for (int b0 = 0; b0 < nblocks; b0 += 3) {
+			float gx[3], gy[3];
+			int at[3];
+#pragma unroll
+			for (int u = 0; u < 3; u++) {
+				const int b = b0 + u;
+				const int by = b / blocksPerSide, bx = b - by * blocksPerSide;
+				const int iy = 8 * by + ly, ix = 8 * bx + lx;
+				const bool on = b < nblocks && iy < gridW && ix < gridW;
+				at[u] = on ? iy * gridW + ix : -1;
+				gx[u] = 0.0f; gy[u] = 0.0f;
+				if (on && G.anyInside) {
+					const int rY = iy - regionR - overLap, rX = ix - regionR - overLap;
+					const double regionY = rY * scale;
+					const double regionX = rX * scale;
+					const int pixelX = (int)(c_x + c * regionX - s * regionY);
+					const int pixelY = (int)(c_y + s * regionX + c * regionY);
+					gradSample(d, G, pixelX, pixelY, gx[u], gy[u]);
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 3; u++)
+				if (at[u] >= 0) { sX[at[u]] = gx[u]; sY[at[u]] = gy[u]; }
 		}
 	}
 	waveSync();
+	DSTAMP(4);
 	const int dof = T.dof;
-	const int T_w = T.widthSubRegion + 2 * overLap;  // samples per sub-region side
+	const int T_w = T.widthSubRegion + 2 * overLap;  // samples per sub-region side (<= TWT, enforced on the host)
 	for (int f = lane; f < dof; f += 64) {
 		const int sub = f >> 2, comp = f & 3;
 		const int suby = sub / T.widthLargeGrid, subx = sub - suby * T.widthLargeGrid;
 		const int rY = -regionR + suby * T.widthSubRegion, rX = -regionR + subx * T.widthSubRegion;
 		double sum = 0;
 		for (int i = 0; i < T_w; i++) {
-			int index = (rY + regionR + i) * gridW + rX + regionR;
-			for (int j = 0; j < T_w; j++, index++) {
-				const double w = T.stable ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
-				const double dx = w * (double)sX[index];
-				const double dy = w * (double)sY[index];
-				const double pdx = c * dx + s * dy;
-				const double pdy = -s * dx + c * dy;
-				const double v = comp < 2 ? pdx : pdy;
-				sum += (comp & 1) ? fabs(v) : v;
+			const int index = (rY + regionR + i) * gridW + rX + regionR;
+			// one wait per row: the row's samples and weights are fetched together, then summed in the reference's order
+			float vx[TWT], vy[TWT];
+			double w[TWT];
+#pragma unroll
+			for (int j = 0; j < TWT; j++) {
+				const bool on = j < T_w;
+				vx[j] = on ? sX[index + j] : 0.0f;
+				vy[j] = on ? sY[index + j] : 0.0f;
+				w[j] = !on ? 0.0 : T.stable ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
+			}
+#pragma unroll
+			for (int j = 0; j < TWT; j++) {
+				if (j < T_w) {
+					const double dx = w[j] * (double)vx[j];
+					const double dy = w[j] * (double)vy[j];
+					const double pdx = c * dx + s * dy;
+					const double pdy = -s * dx + c * dy;
+					const double v = comp < 2 ? pdx : pdy;
+					sum += (comp & 1) ? fabs(v) : v;
+				}
 			}
 		}
 		if (T.stable) sum = T.weightGrid[sub] * sum;
 		feat[f] = sum;
 	}
 	waveSync();
+	DSTAMP(5);
 	// normalizeL2: sequential sum of squares
 	double norm = 0;
 	if (lane == 0) {
-		for (int i = 0; i < dof; i++) { const double v = feat[i]; norm += v * v; }
+		for (int i0 = 0; i0 < dof; i0 += 8) {
+			double v[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) v[k] = i0 + k < dof ? feat[i0 + k] : 0.0;
+#pragma unroll
+			for (int k = 0; k < 8; k++) if (i0 + k < dof) norm += v[k] * v[k];
+		}
 	}
 	norm = __shfl(norm, 0, 64);
 	double* out = P.desc + g * dof;
@@ -308,11 +686,12 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		lap += (double)yy;
 		P.white[g] = lap > 0 ? 1 : 0;
 	}
+	DSTAMP(6);
 }
 
 int bhip_describe_lds_bytes(const SurfTables& t) {
 	const int n = t.oriWidth * t.oriWidth;
-	const int ori = n * (3 * 8 + 4);
+	const int ori = n * (4 * 8 + 2 * 2) + 16;  // dX, dY, two key buffers (double) + two index buffers (u16)
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
@@ -328,13 +707,56 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	P.ii = ii; P.kps = kps; P.cap = cap; P.imageStart = imageStart; P.batch = batch; P.singleImage = singleImage; P.total = total; P.t = t;
 	P.anglesIn = anglesIn; P.angles = angles; P.desc = desc; P.white = white;
 	P.ldsPerWave = bhip_describe_lds_bytes(t);
-	P.gridW = 0;
+	P.stamps = nullptr;
+	{ const char* e = getenv("BHIP_DESCRIBE_SERIAL"); P.serialOnly = (e && e[0] == '1') ? 1 : 0; }
+	if (t.oriWidth * t.oriWidth > 64 * ORI_EPL_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation sample grid too large for the GPU path");
+	if (t.widthSubRegion + 2 * (t.stable ? t.overLap : 0) > DESC_ROW_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "SURF sub-region too wide for the GPU path");
 	if (P.ldsPerWave * 4 > 160 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation/descriptor sample grid too large for LDS");
 	const long long blocks = (total + 3) / 4;
 	if (blocks > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_INVALID, "too many key points");
+	const char* stampPath = getenv("BHIP_DESCRIBE_STAMPS");
+	if (stampPath && total > 1000) {
+		// diagnostic build: phase shares of the describe kernel (never a quoted run time)
+		unsigned long long* dev = nullptr;
+		if (hipMalloc(&dev, (size_t)total * 64) == hipSuccess) {
+			(void)hipMemsetAsync(dev, 0, (size_t)total * 64, ctx->stream);
+			P.stamps = dev;
+			{
+				const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
+				const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
+				if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<true, 5, 9>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+				else hipLaunchKernelGGL((k_describe<true, 8, 16>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+			}
+			std::vector<unsigned long long> h((size_t)total * 8);
+			(void)hipMemcpy(h.data(), dev, (size_t)total * 64, hipMemcpyDeviceToHost);
+			(void)hipFree(dev);
+			double sum[7] = {0};
+			long long cnt = 0;
+			for (long long k = 0; k < total; k++) {
+				const unsigned long long* tt = &h[(size_t)k * 8];
+				if (!tt[6] || !tt[0]) continue;
+				for (int i = 1; i <= 6; i++) sum[i] += (double)(tt[i] - tt[i - 1]);
+				cnt++;
+			}
+			FILE* f = fopen(stampPath, "a");
+			if (f && cnt) {
+				fprintf(f, "waves %lld  avg cycles: samples %.0f  sort %.0f  window+atan2 %.0f  descSamples %.0f  sums %.0f  norm+laplace %.0f\n", cnt,
+						sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt);
+			}
+			if (f) fclose(f);
+			BHIP_HIP(ctx, hipGetLastError());
+			return BHIP_OK;
+		}
+	}
 	{
 		ProfScope ps(ctx, "k_describe");
-		hipLaunchKernelGGL(k_describe, dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+		const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
+		const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
+		const dim3 grid((unsigned)blocks), block(256);
+		const size_t ldsBytes = (size_t)P.ldsPerWave * 4;
+		if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9>), grid, block, ldsBytes, ctx->stream, P);        // surfStable defaults
+		else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5>), grid, block, ldsBytes, ctx->stream, P);   // surfFast defaults
+		else hipLaunchKernelGGL((k_describe<false, 8, 16>), grid, block, ldsBytes, ctx->stream, P);
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

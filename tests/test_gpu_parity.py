@@ -490,3 +490,28 @@ def test_batched_device_association(api, orc):
     for k in range(n):
         p, f = orc.associate_l2(sets[k], sets[dst_idx[k]], api.Double_MAX_VALUE, True)
         assert np.array_equal(pairs[starts[k]:starts[k + 1]], p) and np.array_equal(fit[starts[k]:starts[k + 1]], f), k
+
+
+def test_orientation_degenerate_regimes(api, orc):
+    """Planar ramps (all gradients parallel: the sliding window wraps the full circle), flat patches (all angles equal) and points
+    whose sample grid leaves the image (zero gradients) -- GenericOrientationIntegralTests.java:98-170 through the full pipeline."""
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32)
+    ref = orc.Surf(True)
+    yy, xx = np.mgrid[0:100, 0:120]
+    for k, theta in enumerate([0.0, 0.5, math.pi / 2, 2.0, -1.2, 3.0, -3.1]):
+        a = (10 * (xx * math.cos(theta) + yy * math.sin(theta))).astype(np.float32)
+        img = orc.Gray.from_array(a + 500.0)
+        dd.detect(G(api, img))
+        pts = np.array([[60, 50, 2.0], [60.5, 50.25, 3.7], [30, 70, 1.2], [2, 2, 2.0], [118, 97, 2.5], [60, 3, 5.0]])
+        ang, white, desc = dd.describePoints(pts)
+        ref.describe_points(pts, img)
+        _, rang, rwhite, rdesc = ref.fetch()
+        assert np.max(np.abs(np.angle(np.exp(1j * (ang - rang))))) < 1e-9, theta
+        assert np.max(np.abs(desc - rdesc)) <= DESC_TOL and np.array_equal(white, rwhite)
+        assert abs(np.angle(np.exp(1j * (ang[0] - theta)))) < math.pi / 9
+    flat = orc.Gray.from_array(np.full((100, 120), 50, np.float32))
+    dd.detect(G(api, flat))
+    ang, white, desc = dd.describePoints(pts)
+    ref.describe_points(pts, flat)
+    _, rang, rwhite, rdesc = ref.fetch()
+    assert np.array_equal(ang, rang) and np.array_equal(desc, rdesc) and np.all(desc == 0)
