@@ -26,6 +26,11 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 								 int* usedMfma);
 void bhip_assoc_mfma_release(AssocMfmaWork& W);
 
+bool bhip_fused_plan(int skip, int nlevels, const int* sizes, int radius, int* TX, int* TY, int* ldsBytes);
+int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, int nmid, const DetectLevelParams* mids,
+							 const int* midLevels, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
+							 int cap);
+
 // per-context scratch that the stateless entry points reuse
 struct CtxScratch {
 	DevBuf a, b, c, d, e, work;
@@ -136,6 +141,11 @@ struct FhDetector {
 	std::vector<int> counts;   // per image, host
 	long long total = 0;
 
+	static bool unfusedOnly() {
+		static int v = -1;
+		if (v < 0) { const char* e = getenv("BHIP_DETECT_UNFUSED"); v = (e && e[0] == '1') ? 1 : 0; }  // parity cross-check of the two detector paths
+		return v == 1;
+	}
 	int makePlan(bhip_ctx* ctx, int width, int height) {
 		plan.clear();
 		if (cfg.numberScalesPerOctave > BHIP_MAX_LEVELS || cfg.numberScalesPerOctave < 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "numberScalesPerOctave out of range");
@@ -202,6 +212,16 @@ struct FhDetector {
 			BHIP_HIP(ctx, hipMemsetAsync(bitmap.p, 0, (size_t)bitmapWords * 4 * batch, ctx->stream));
 			BHIP_HIP(ctx, hipMemsetAsync(count.p, 0, (size_t)batch * 4 * 2, ctx->stream));
 			for (auto& o : plan) {
+				int ftx, fty, flds;
+				if (!unfusedOnly() && !o.mids.empty() && bhip_fused_plan(o.skip, o.nlevels, o.sizes, cfg.extractRadius, &ftx, &fty, &flds)) {
+					// LDS-tiled fused octave: intensity never leaves the CU
+					DetectLevelParams mp[BHIP_MAX_LEVELS];
+					int ml[BHIP_MAX_LEVELS];
+					for (size_t k = 0; k < o.mids.size(); k++) { mp[k] = o.mids[k].p; ml[k] = o.mids[k].level; }
+					BHIP_TRY(bhip_launch_detect_fused(ctx, ii, batch, o.skip, o.nlevels, o.sizes, (int)o.mids.size(), mp, ml, cfg.extractRadius,
+													  cfg.detectThreshold, bitmap.as<unsigned int>(), bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap));
+					continue;
+				}
 				const long long levelStride = (long long)o.w * o.h;
 				const long long imageStride = levelStride * o.nlevels;
 				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, inten.as<float>(), levelStride, imageStride, o.w));

@@ -1,0 +1,556 @@
+// K2+K3 fused: one octave of the Fast-Hessian detector per launch, LDS tiled.  The four intensity levels of a tile are built in LDS from
+// an LDS copy of the integral-image patch and consumed there by the non-maximum / scale-space test -- the intensity images never
+// reach HBM.  Arithmetic and decisions are the same as the stand-alone kernels (hessian.hip, detect.hip), so key points stay bit-exact.
+//
+// Reference: IntegralImageFeatureIntensity.hessian (F:alg/feature/detect/intensity/IntegralImageFeatureIntensity.java:43-56,
+//            impl/ImplIntegralImageFeatureIntensity.java:72-213), NonMaxBlock / NonMaxBlockSearchStrict.Max
+//            (F:alg/feature/detect/extract/NonMaxBlock.java:69-94, NonMaxBlockSearchStrict.java:56-79,196-221),
+//            FastHessianFeatureDetector.detectOctave / findLocalScaleSpaceMax / checkMax / polyPeak
+//            (F:alg/feature/detect/interest/FastHessianFeatureDetector.java:198-350).
+//
+// Tile: TX x TY output pixels plus a halo of `radius` (the NMS neighbourhood; the 3x3 scale-space test needs 1), ITW = TX + 2*halo is a
+// power of two so an item index splits into (row, column) with shifts.  ii patch = every tap any inner pixel of the tile can touch:
+// [(x0-halo)*skip - rFmax - 1, (x0+TX-1+halo)*skip + rFmax].  Pixels that need the reference's clamped border formula (hessianBorder)
+// read the integral image from global memory; they only exist in tiles along the image frame.
+// Bound: HBM by the algorithmic count (ii read once per octave, nothing written but key points); in practice LDS-read / issue bound:
+// 32 taps per intensity value.
+#include "common.h"
+#include <cfloat>
+
+struct FusedLevel {
+	int size;
+	int bS, bL, rF, rS;
+	int border, lost;
+	float norm;
+	int r1, r2, r3, b;
+};
+struct FusedMid {
+	int level;            // index of the mid level
+	int border;           // ignoreBorder = size/(2*skip)
+	int nbx;              // NMS blocks per row
+	unsigned int bitBase;
+	int sizeMid, sizeLower;
+};
+struct FusedParams {
+	ImgView ii;
+	int skip, w, h, nlevels;
+	FusedLevel lv[BHIP_MAX_LEVELS];
+	int TX, TY, HR, ITW, ITWlog, ITH, ITp;   // tile geometry (intensity space); ITp = LDS pitch of an intensity row
+	int IW, IH, IWp, rFmax;                   // ii patch geometry
+	int radius;
+	float threshold;
+	int nmid;
+	FusedMid mid[BHIP_MAX_LEVELS];
+	unsigned int* bitmap;
+	int bitmapWords;
+	KeyPoint* cand;
+	int* candCount;
+	int cap;
+	int ablate;   // timing experiments only (BHIP_FUSED_ABLATE): 1 skip the intensity phase, 2 skip the NMS phase, 4 skip staging
+};
+
+__device__ __forceinline__ float fblock_zero(const float* __restrict__ d, int stride, int W, int H, int x0, int y0, int x1, int y1) {
+	x0 = min(x0, W - 1); y0 = min(y0, H - 1); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+	float br = 0, tr = 0, bl = 0, tl = 0;
+	if (x1 >= 0 && y1 >= 0) br = d[(long long)y1 * stride + x1];
+	if (y0 >= 0 && x1 >= 0) tr = d[(long long)y0 * stride + x1];
+	if (x0 >= 0 && y1 >= 0) bl = d[(long long)y1 * stride + x0];
+	if (x0 >= 0 && y0 >= 0) tl = d[(long long)y0 * stride + x0];
+	return br - tr - bl + tl;
+}
+// block_zero on the staged patch: every clamped corner of a pixel of this tile lies inside the patch (clamping only moves a corner
+// towards the pixel), so the reference's border formula needs no global memory either.
+__device__ __forceinline__ float lblock_zero(const float* iiT, int pitch, int X0, int Y0, int W, int H, int x0, int y0, int x1, int y1) {
+	x0 = min(x0, W - 1); y0 = min(y0, H - 1); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+	const int cx0 = max(x0, 0) - X0, cy0 = max(y0, 0) - Y0, cx1 = max(x1, 0) - X0, cy1 = max(y1, 0) - Y0;
+	const float vbr = iiT[cy1 * pitch + cx1], vtr = iiT[cy0 * pitch + cx1], vbl = iiT[cy1 * pitch + cx0], vtl = iiT[cy0 * pitch + cx0];
+	const float br = (x1 >= 0 && y1 >= 0) ? vbr : 0.0f;
+	const float tr = (y0 >= 0 && x1 >= 0) ? vtr : 0.0f;
+	const float bl = (x0 >= 0 && y1 >= 0) ? vbl : 0.0f;
+	const float tl = (x0 >= 0 && y0 >= 0) ? vtl : 0.0f;
+	return br - tr - bl + tl;
+}
+__device__ __forceinline__ float fpolyPeak(float lower, float middle, float upper) {
+	const float a = 0.5f * lower - middle + 0.5f * upper;
+	const float b = 0.5f * upper - 0.5f * lower;
+	if (a == 0.0f) return 0.0f;
+	return -b / (2.0f * a);
+}
+
+__global__ __launch_bounds__(256) void k_detect_fused(FusedParams P) {
+	extern __shared__ __attribute__((aligned(16))) float fl[];
+	float* iiT = fl;                                  // [IH][IWp]
+	float* inten = fl + (size_t)P.IH * P.IWp;         // [nlevels][ITH][ITp]
+	const int tid = threadIdx.x;
+	const int img = blockIdx.z;
+	const int x0 = blockIdx.x * P.TX, y0 = blockIdx.y * P.TY;
+	const int s = P.skip;
+	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
+	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
+	const int X0 = (x0 - P.HR) * s - P.rFmax - 1, Y0 = (y0 - P.HR) * s - P.rFmax - 1;
+
+	// ---- stage the integral-image patch (rows of IW floats, coalesced)
+	if (!(P.ablate & 4)) {
+		const int tx = tid & 63, ty = tid >> 6;
+		for (int ry = ty; ry < P.IH; ry += 4) {
+			const int gy = Y0 + ry;
+			const bool rowOk = gy >= 0 && gy < H;
+			const float* __restrict__ src = d + (long long)(rowOk ? gy : 0) * stride;
+			for (int rx = tx; rx < P.IW; rx += 64) {
+				const int gx = X0 + rx;
+				iiT[ry * P.IWp + rx] = (rowOk && gx >= 0 && gx < W) ? src[gx] : 0.0f;
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- intensity of every level over the tile + halo
+	const int itemsPerLevel = P.ITH << P.ITWlog;
+	for (int L = 0; L < ((P.ablate & 1) ? 0 : P.nlevels); L++) {
+		const FusedLevel V = P.lv[L];
+		float* out = inten + (size_t)L * P.ITH * P.ITp;
+		// tap offsets inside the patch, relative to (xx - X0, yy - Y0)
+		const int bS = V.bS;
+		const int cxx = -V.rF - 1, rxx = -V.rS - 1;           // Dxx: first column / top row
+		const int cyy = -V.rS - 1, ryy = -V.rF - 1;           // Dyy: left column / first row
+		const int cxy = -bS - 1, rxy = -bS - 1;               // Dxy
+		for (int it = tid; it < itemsPerLevel; it += 256) {
+			const int px = it & (P.ITW - 1), py = it >> P.ITWlog;
+			const int x = x0 - P.HR + px, y = y0 - P.HR + py;
+			float det;
+			if (x < 0 || x >= P.w || y < 0 || y >= P.h) {
+				det = -INFINITY;  // outside the image: never >= anything, as if the neighbourhood were clamped
+			} else {
+				const int xx = x * s, yy = y * s;
+				float Dxx, Dyy, Dxy;
+				const bool inner = x >= V.border && x < P.w - V.border && y >= V.border && y < P.h - V.border;
+				if (inner) {
+					const int lx = xx - X0, ly = yy - Y0;
+					const int pitch = P.IWp;
+					{
+						const float* t = iiT + (ly + rxx) * pitch + lx + cxx;
+						const float* bt = t + V.bL * pitch;
+						Dxx = bt[3 * bS] - t[3 * bS] - bt[0] + t[0];
+						Dxx -= 3 * (bt[2 * bS] - t[2 * bS] - bt[bS] + t[bS]);
+					}
+					{
+						const float* l = iiT + (ly + ryy) * pitch + lx + cyy;
+						const float* r = l + V.bL;
+						const int ro1 = bS * pitch;
+						Dyy = r[3 * ro1] - l[3 * ro1] - r[0] + l[0];
+						Dyy -= 3 * (r[2 * ro1] - l[2 * ro1] - r[ro1] + l[ro1]);
+					}
+					{
+						const float* y1 = iiT + (ly + rxy) * pitch + lx + cxy;
+						const float* y2 = y1 + bS * pitch;
+						const float* y3 = y2 + pitch;
+						const float* y4 = y3 + bS * pitch;
+						const int x3 = bS + 1, x4 = x3 + bS;
+						Dxy = y2[bS] - y1[bS] - y2[0] + y1[0];
+						Dxy -= y2[x4] - y1[x4] - y2[x3] + y1[x3];
+						Dxy += y4[x4] - y3[x4] - y4[x3] + y3[x3];
+						Dxy -= y4[bS] - y3[bS] - y4[0] + y3[0];
+					}
+				} else {
+					const int pitch = P.IWp;
+					float ret = 0;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx - V.r2 - 1, yy - V.r3 - 1, xx + V.r2, yy + V.r3) * 1.0f;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx - V.r1 - 1, yy - V.r3 - 1, xx + V.r1, yy + V.r3) * -3.0f;
+					Dxx = ret;
+					ret = 0;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx - V.r3 - 1, yy - V.r2 - 1, xx + V.r3, yy + V.r2) * 1.0f;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx - V.r3 - 1, yy - V.r1 - 1, xx + V.r3, yy + V.r1) * -3.0f;
+					Dyy = ret;
+					ret = 0;
+					const int b = V.b;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * 1.0f;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * -1.0f;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx, yy, xx + b, yy + b) * 1.0f;
+					ret += lblock_zero(iiT, pitch, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * -1.0f;
+					Dxy = ret;
+				}
+				Dxx *= V.norm;
+				Dxy *= V.norm;
+				Dyy *= V.norm;
+				det = Dxx * Dyy - 0.81f * Dxy * Dxy;
+			}
+			out[py * P.ITp + px] = det;
+		}
+	}
+	__syncthreads();
+
+	// ---- strict (2r+1)^2 maximum + scale-space test on the mid levels, from LDS
+	const int r = P.radius;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int rows = (P.ablate & 2) ? 0 : P.nmid * P.TY;
+	for (int row = wave; row < rows; row += 4) {
+		const int m = row / P.TY;
+		const int py = row - m * P.TY;
+		for (int px = lane; px < P.TX; px += 64) {
+			const FusedMid M = P.mid[m];
+			const int x = x0 + px, y = y0 + py;
+			const int b = M.border;
+			if (x < b || x >= P.w - b || y < b || y >= P.h - b) continue;
+			const float* mid = inten + (size_t)M.level * P.ITH * P.ITp + (py + P.HR) * P.ITp + (px + P.HR);
+			const float val = mid[0];
+			if (!(val >= P.threshold) || val == FLT_MAX) continue;
+			bool isMax = true;
+			for (int j = -r; j <= r && isMax; j++)
+				for (int i = -r; i <= r; i++) {
+					if ((i | j) != 0 && mid[j * P.ITp + i] >= val) { isMax = false; break; }
+				}
+			if (!isMax) continue;
+			const int ignoreR = b + r;
+			if (x < ignoreR || x >= P.w - ignoreR || y < ignoreR || y >= P.h - ignoreR) continue;
+			const float* lower = mid - (size_t)P.ITH * P.ITp;
+			const float* upper = mid + (size_t)P.ITH * P.ITp;
+			bool ok = true;
+			for (int j = -1; j <= 1 && ok; j++)
+				for (int i = -1; i <= 1; i++) {
+					if (lower[j * P.ITp + i] >= val || upper[j * P.ITp + i] >= val) { ok = false; break; }
+				}
+			if (!ok) continue;
+			const float peakX = fpolyPeak(mid[-1], val, mid[1]);
+			const float peakY = fpolyPeak(mid[-P.ITp], val, mid[P.ITp]);
+			const float peakS = fpolyPeak(lower[0], val, upper[0]);
+			const float interpX = ((float)x + peakX) * (float)s;
+			const float interpY = ((float)y + peakY) * (float)s;
+			const float interpS = (float)M.sizeMid + peakS * (float)(M.sizeMid - M.sizeLower);
+			const double scale = 1.2 * (double)interpS / 9.0;
+			const int step = r + 1;
+			const unsigned int bit = M.bitBase + (unsigned)((y - b) / step) * (unsigned)M.nbx + (unsigned)((x - b) / step);
+			atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+			const int slot = atomicAdd(&P.candCount[img], 1);
+			if (slot < P.cap) {
+				KeyPoint kp;
+				kp.x = (double)interpX;
+				kp.y = (double)interpY;
+				kp.scale = scale;
+				kp.key = bit;
+				kp.pad = 0;
+				P.cand[(long long)img * P.cap + slot] = kp;
+			}
+		}
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Compile-time geometry variant for the reference's default schedule (sizes SIZE0 + i*STEPSZ, NL levels, NMS radius R): every tap
+// offset becomes an immediate of a ds_read, pairs of taps in one row fuse into ds_read2, and the address arithmetic per intensity value
+// shrinks to one base.  Same arithmetic, same decisions as k_detect_fused.
+template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
+struct FixedGeo {
+	static constexpr int TX = ITWT - 2 * R, TY = TYT, ITW = ITWT, ITH = TYT + 2 * R, ITp = ITWT + 1;
+	static constexpr int sizeMax = SIZE0 + (NL - 1) * STEPSZ;
+	static constexpr int rFmax = sizeMax / 2;
+	static constexpr int IW = (TX - 1 + 2 * R) * SKIP + 2 * rFmax + 2, IH = (TY - 1 + 2 * R) * SKIP + 2 * rFmax + 2;
+	// The patch is stored as SKIP column-phase planes: element (row, col) lives at plane (col % SKIP), row, col / SKIP.  A tap of the
+	// lanes' consecutive output pixels (columns xx = x*SKIP apart) then reads consecutive LDS words -- no bank conflicts for SKIP > 1.
+	static constexpr int IWp = ((IW + SKIP - 1) / SKIP) | 1;      // pitch of one plane row
+	static constexpr int plane = IH * IWp;
+	static constexpr int ldsFloats = SKIP * plane + NL * ITH * ITp;
+	static constexpr int K0 = rFmax + 1;                          // column of (xx) inside the patch, minus SKIP*(x - x0 + R)
+	// LDS offset of the tap at (row offset ro, column offset co) relative to the pixel's base pointer (row yy-Y0, column slot x-x0+R)
+	static constexpr int tap(int ro, int co) { return ((K0 + co) % SKIP) * plane + ro * IWp + (K0 + co) / SKIP; }
+	// run-time form for the border formula: absolute patch coordinates (r, c) -> LDS index
+	static __device__ __forceinline__ int at(int r, int c) { return (c % SKIP) * plane + r * IWp + c / SKIP; }
+	static constexpr int size(int L) { return SIZE0 + L * STEPSZ; }
+	static constexpr int bS(int L) { return size(L) / 3; }
+	static constexpr int bL(int L) { return size(L) - bS(L) - 1; }
+	static constexpr int rF(int L) { return size(L) / 2; }
+	static constexpr int rS(int L) { return bL(L) / 2; }
+	static constexpr int border(int L) { return (rF(L) + 1 + (SKIP - (rF(L) + 1) % SKIP)) / SKIP; }
+};
+
+// block_zero on the phase-plane patch (see lblock_zero)
+template <class G>
+__device__ __forceinline__ float pblock_zero(const float* iiT, int X0, int Y0, int W, int H, int x0, int y0, int x1, int y1) {
+	x0 = min(x0, W - 1); y0 = min(y0, H - 1); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
+	const int cx0 = max(x0, 0) - X0, cy0 = max(y0, 0) - Y0, cx1 = max(x1, 0) - X0, cy1 = max(y1, 0) - Y0;
+	const float vbr = iiT[G::at(cy1, cx1)], vtr = iiT[G::at(cy0, cx1)], vbl = iiT[G::at(cy1, cx0)], vtl = iiT[G::at(cy0, cx0)];
+	const float br = (x1 >= 0 && y1 >= 0) ? vbr : 0.0f;
+	const float tr = (y0 >= 0 && x1 >= 0) ? vtr : 0.0f;
+	const float bl = (x0 >= 0 && y1 >= 0) ? vbl : 0.0f;
+	const float tl = (x0 >= 0 && y0 >= 0) ? vtl : 0.0f;
+	return br - tr - bl + tl;
+}
+
+template <class G, int SKIP, int NL, int R, int L>
+__device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const float* __restrict__ d, const float* iiT, float* inten, int tid, int x0, int y0,
+												 int X0, int Y0) {
+	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), rF = G::rF(L), rS = G::rS(L), border = G::border(L);
+	constexpr float norm = 1.0f / (float)(size * size);
+	constexpr int pitch = G::IWp;
+	constexpr int r1 = bS / 2, r2 = bS + r1, r3 = bLg / 2, b = bS;
+	float* out = inten + L * G::ITH * G::ITp;
+	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
+#pragma unroll 1
+	for (int it = tid; it < G::ITH * G::ITW; it += 256) {
+		const int px = it & (G::ITW - 1), py = it / G::ITW;
+		const int x = x0 - R + px, y = y0 - R + py;
+		float det;
+		if (x < 0 || x >= P.w || y < 0 || y >= P.h) {
+			det = -INFINITY;
+		} else {
+			const int xx = x * SKIP, yy = y * SKIP;
+			float Dxx, Dyy, Dxy;
+			const bool inner = x >= border && x < P.w - border && y >= border && y < P.h - border;
+			if (inner) {
+				const float* c = iiT + (yy - Y0) * pitch + (x - x0 + R);   // base: patch row of yy, column slot of x
+#define TAP(ro, co) c[G::tap((ro), (co))]
+				{
+					constexpr int rt = -rS - 1, rb = rt + bLg, c0 = -rF - 1;
+					Dxx = TAP(rb, c0 + 3 * bS) - TAP(rt, c0 + 3 * bS) - TAP(rb, c0) + TAP(rt, c0);
+					Dxx -= 3 * (TAP(rb, c0 + 2 * bS) - TAP(rt, c0 + 2 * bS) - TAP(rb, c0 + bS) + TAP(rt, c0 + bS));
+				}
+				{
+					constexpr int r0 = -rF - 1, cl = -rS - 1, cr = cl + bLg;
+					Dyy = TAP(r0 + 3 * bS, cr) - TAP(r0 + 3 * bS, cl) - TAP(r0, cr) + TAP(r0, cl);
+					Dyy -= 3 * (TAP(r0 + 2 * bS, cr) - TAP(r0 + 2 * bS, cl) - TAP(r0 + bS, cr) + TAP(r0 + bS, cl));
+				}
+				{
+					constexpr int ry1 = -bS - 1, ry2 = ry1 + bS, ry3 = ry2 + 1, ry4 = ry3 + bS, c0 = -bS - 1;
+					constexpr int x3 = bS + 1, x4 = x3 + bS;
+					Dxy = TAP(ry2, c0 + bS) - TAP(ry1, c0 + bS) - TAP(ry2, c0) + TAP(ry1, c0);
+					Dxy -= TAP(ry2, c0 + x4) - TAP(ry1, c0 + x4) - TAP(ry2, c0 + x3) + TAP(ry1, c0 + x3);
+					Dxy += TAP(ry4, c0 + x4) - TAP(ry3, c0 + x4) - TAP(ry4, c0 + x3) + TAP(ry3, c0 + x3);
+					Dxy -= TAP(ry4, c0 + bS) - TAP(ry3, c0 + bS) - TAP(ry4, c0) + TAP(ry3, c0);
+				}
+#undef TAP
+			} else {
+				float ret = 0;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * 1.0f;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * -3.0f;
+				Dxx = ret;
+				ret = 0;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * 1.0f;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * -3.0f;
+				Dyy = ret;
+				ret = 0;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * 1.0f;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * -1.0f;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * 1.0f;
+				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * -1.0f;
+				Dxy = ret;
+			}
+			Dxx *= norm;
+			Dxy *= norm;
+			Dyy *= norm;
+			det = Dxx * Dyy - 0.81f * Dxy * Dxy;
+		}
+		out[py * G::ITp + px] = det;
+	}
+	if constexpr (L + 1 < NL) fusedLevelFixed<G, SKIP, NL, R, L + 1>(P, d, iiT, inten, tid, x0, y0, X0, Y0);
+}
+
+template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
+__global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
+	typedef FixedGeo<SKIP, SIZE0, STEPSZ, NL, R, ITWT, TYT> G;
+	extern __shared__ __attribute__((aligned(16))) float fl[];
+	float* iiT = fl;
+	float* inten = fl + SKIP * G::plane;
+	const int tid = threadIdx.x;
+	int bx = blockIdx.x, by = blockIdx.y, img = blockIdx.z;
+	if (P.ablate & 16) {   // experiment: 1-D grid, image-major
+		const int tilesX = (P.w + G::TX - 1) / G::TX, tilesY = (P.h + G::TY - 1) / G::TY;
+		const int lin = blockIdx.x;
+		img = lin / (tilesX * tilesY);
+		const int rem = lin - img * tilesX * tilesY;
+		by = rem / tilesX;
+		bx = rem - by * tilesX;
+	}
+	const int x0 = bx * G::TX, y0 = by * G::TY;
+	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
+	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
+	const int X0 = (x0 - R) * SKIP - G::rFmax - 1, Y0 = (y0 - R) * SKIP - G::rFmax - 1;
+	{
+		// stage the patch: every thread keeps a batch of independent global loads in flight before the first LDS store
+		const int tx = tid & 63, ty = tid >> 6;
+		constexpr int COLS = (G::IW + 63) / 64;   // 64-float column chunks per row
+		constexpr int RB = COLS >= 2 ? 4 : 6;     // rows per batch
+		for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
+			float v[RB][COLS];
+#pragma unroll
+			for (int k = 0; k < RB; k++) {
+				const int ry = ry0 + 4 * k;
+				const int gy = Y0 + ry;
+				const bool rowOk = ry < G::IH && gy >= 0 && gy < H;
+				const float* __restrict__ src = d + (long long)(rowOk ? gy : 0) * stride;
+#pragma unroll
+				for (int cc = 0; cc < COLS; cc++) {
+					const int rx = cc * 64 + tx;
+					const int gx = X0 + rx;
+					const bool ok = rowOk && rx < G::IW && gx >= 0 && gx < W;
+					v[k][cc] = src[ok ? gx : 0];
+					if (!ok) v[k][cc] = 0.0f;
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < RB; k++) {
+				const int ry = ry0 + 4 * k;
+#pragma unroll
+				for (int cc = 0; cc < COLS; cc++) {
+					const int rx = cc * 64 + tx;
+					if (ry < G::IH && rx < G::IW) iiT[G::at(ry, rx)] = v[k][cc];
+				}
+			}
+		}
+	}
+	__syncthreads();
+	fusedLevelFixed<G, SKIP, NL, R, 0>(P, d, iiT, inten, tid, x0, y0, X0, Y0);
+	__syncthreads();
+
+	const int wave = tid >> 6, lane = tid & 63;
+	const int rows = P.nmid * G::TY;
+	for (int row = wave; row < rows; row += 4) {
+		const int m = row / G::TY;
+		const int py = row - m * G::TY;
+		const int px = lane;
+		if (px >= G::TX) continue;
+		const FusedMid M = P.mid[m];
+		const int x = x0 + px, y = y0 + py;
+		const int b = M.border;
+		if (x < b || x >= P.w - b || y < b || y >= P.h - b) continue;
+		const float* mid = inten + M.level * (G::ITH * G::ITp) + (py + R) * G::ITp + (px + R);
+		const float val = mid[0];
+		if (!(val >= P.threshold) || val == FLT_MAX) continue;
+		// the whole (2R+1)^2 neighbourhood in one batch of LDS reads
+		float nb[(2 * R + 1) * (2 * R + 1)];
+#pragma unroll
+		for (int j = -R; j <= R; j++)
+#pragma unroll
+			for (int i = -R; i <= R; i++) nb[(j + R) * (2 * R + 1) + (i + R)] = mid[j * G::ITp + i];
+		bool isMax = true;
+#pragma unroll
+		for (int k = 0; k < (2 * R + 1) * (2 * R + 1); k++)
+			if (k != R * (2 * R + 1) + R && nb[k] >= val) isMax = false;
+		if (!isMax) continue;
+		const int ignoreR = b + R;
+		if (x < ignoreR || x >= P.w - ignoreR || y < ignoreR || y >= P.h - ignoreR) continue;
+		const float* lower = mid - G::ITH * G::ITp;
+		const float* upper = mid + G::ITH * G::ITp;
+		float lo9[9], up9[9];
+#pragma unroll
+		for (int j = -1; j <= 1; j++)
+#pragma unroll
+			for (int i = -1; i <= 1; i++) { lo9[(j + 1) * 3 + i + 1] = lower[j * G::ITp + i]; up9[(j + 1) * 3 + i + 1] = upper[j * G::ITp + i]; }
+		bool ok = true;
+#pragma unroll
+		for (int k = 0; k < 9; k++)
+			if (lo9[k] >= val || up9[k] >= val) ok = false;
+		if (!ok) continue;
+		const float peakX = fpolyPeak(nb[R * (2 * R + 1) + R - 1], val, nb[R * (2 * R + 1) + R + 1]);
+		const float peakY = fpolyPeak(nb[(R - 1) * (2 * R + 1) + R], val, nb[(R + 1) * (2 * R + 1) + R]);
+		const float peakS = fpolyPeak(lo9[4], val, up9[4]);
+		const float interpX = ((float)x + peakX) * (float)SKIP;
+		const float interpY = ((float)y + peakY) * (float)SKIP;
+		const float interpS = (float)M.sizeMid + peakS * (float)(M.sizeMid - M.sizeLower);
+		const double scale = 1.2 * (double)interpS / 9.0;
+		constexpr int step = R + 1;
+		const unsigned int bit = M.bitBase + (unsigned)((y - b) / step) * (unsigned)M.nbx + (unsigned)((x - b) / step);
+		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+		const int slot = atomicAdd(&P.candCount[img], 1);
+		if (slot < P.cap) {
+			KeyPoint kp;
+			kp.x = (double)interpX;
+			kp.y = (double)interpY;
+			kp.scale = scale;
+			kp.key = bit;
+			kp.pad = 0;
+			P.cand[(long long)img * P.cap + slot] = kp;
+		}
+	}
+}
+
+// Picks the tile geometry for one octave; returns false when the ii patch cannot be held in LDS (the caller then runs the unfused kernels).
+bool bhip_fused_plan(int skip, int nlevels, const int* sizes, int radius, int* TX, int* TY, int* ldsBytes) {
+	int rFmax = 0;
+	for (int i = 0; i < nlevels; i++) rFmax = sizes[i] / 2 > rFmax ? sizes[i] / 2 : rFmax;
+	const int HR = radius;
+	static const int itws[3] = {64, 32, 16};
+	static const int tys[3] = {16, 8, 4};
+	for (int a = 0; a < 3; a++) {
+		const int tx = itws[a] - 2 * HR;
+		if (tx < 4) continue;
+		for (int bidx = 0; bidx < 3; bidx++) {
+			const int ty = tys[bidx];
+			const int IW = (tx - 1 + 2 * HR) * skip + 2 * rFmax + 2, IH = (ty - 1 + 2 * HR) * skip + 2 * rFmax + 2;
+			const int IWp = IW | 1;
+			const int bytes = (IH * IWp + nlevels * (ty + 2 * HR) * (itws[a] + 1)) * 4;
+			if (bytes <= 52 * 1024) {  // three workgroups per CU
+				*TX = tx; *TY = ty; *ldsBytes = bytes;
+				return true;
+			}
+		}
+	}
+	return false;
+}
+
+int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, int nmid, const DetectLevelParams* mids,
+							 const int* midLevels, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
+							 int cap) {
+	FusedParams P;
+	int TX, TY, lds;
+	if (!bhip_fused_plan(skip, nlevels, sizes, radius, &TX, &TY, &lds)) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "octave does not fit the fused tile");
+	P.ii = ii; P.skip = skip; P.w = ii.width / skip; P.h = ii.height / skip; P.nlevels = nlevels;
+	if (P.w <= 0 || P.h <= 0 || nmid <= 0) return BHIP_OK;
+	int rFmax = 0;
+	for (int i = 0; i < nlevels; i++) {
+		const int size = sizes[i];
+		FusedLevel& L = P.lv[i];
+		L.size = size; L.bS = size / 3; L.bL = size - L.bS - 1; L.rF = size / 2; L.rS = L.bL / 2;
+		const int borderOrig = L.rF + 1 + (skip - (L.rF + 1) % skip);
+		L.border = borderOrig / skip; L.lost = borderOrig - L.rF - 1;
+		L.norm = 1.0f / (float)(size * size);
+		const int blockW = size / 3, blockH = size - blockW - 1;
+		L.r1 = blockW / 2; L.r2 = blockW + L.r1; L.r3 = blockH / 2; L.b = size / 3;
+		rFmax = L.rF > rFmax ? L.rF : rFmax;
+	}
+	P.TX = TX; P.TY = TY; P.HR = radius; P.ITW = TX + 2 * radius; P.ITH = TY + 2 * radius; P.ITp = P.ITW + 1;
+	P.ITWlog = 0;
+	while ((1 << P.ITWlog) < P.ITW) P.ITWlog++;
+	P.rFmax = rFmax;
+	P.IW = (TX - 1 + 2 * radius) * skip + 2 * rFmax + 2;
+	P.IH = (TY - 1 + 2 * radius) * skip + 2 * rFmax + 2;
+	P.IWp = P.IW | 1;
+	P.radius = radius; P.threshold = threshold; P.nmid = nmid;
+	for (int m = 0; m < nmid; m++) {
+		P.mid[m].level = midLevels[m]; P.mid[m].border = mids[m].border; P.mid[m].nbx = mids[m].nbx; P.mid[m].bitBase = mids[m].bitBase;
+		P.mid[m].sizeMid = mids[m].sizeMid; P.mid[m].sizeLower = mids[m].sizeLower;
+	}
+	{ const char* e = getenv("BHIP_FUSED_ABLATE"); P.ablate = e ? atoi(e) : 0; }
+	P.bitmap = bitmap; P.bitmapWords = bitmapWords; P.cand = cand; P.candCount = candCount; P.cap = cap;
+	dim3 grid((P.w + TX - 1) / TX, (P.h + TY - 1) / TY, batch);
+	{
+		// algorithmic bytes of the fused octave: the integral image read once (nothing else reaches HBM but the key points)
+		ProfScope ps(ctx, skip == 1 ? "k_detect_fused_skip1" : "k_detect_fused_skipN", 4.0 * ii.width * ii.height * batch);
+		bool launched = false;
+		if (nlevels == 4 && radius == 2 && !(P.ablate & 8)) {
+			const int step = sizes[1] - sizes[0];
+			const bool arith = sizes[2] - sizes[1] == step && sizes[3] - sizes[2] == step;
+			const char* var = getenv("BHIP_FUSED_VARIANT");   // tile-shape experiments
+			const char v = var ? var[0] : 0;
+#define LAUNCH_FIXED(SK, S0, ST, ITWV, TYV)                                                                                             \
+	do {                                                                                                                               \
+		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV> G;                                                                               \
+		dim3 g((P.w + G::TX - 1) / G::TX, (P.h + G::TY - 1) / G::TY, batch);                                                            \
+		hipLaunchKernelGGL((k_detect_fused_fixed<SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
+		launched = true;                                                                                                               \
+	} while (0)
+			if (arith && skip == 1 && sizes[0] == 9 && step == 6) {
+				if (v == 'a') LAUNCH_FIXED(1, 9, 6, 32, 32);
+				else if (v == 'x') LAUNCH_FIXED(1, 9, 6, 64, 16);
+				else LAUNCH_FIXED(1, 9, 6, 32, 16);
+			} else if (arith && skip == 2 && sizes[0] == 15 && step == 12) {
+				if (v == 'a') LAUNCH_FIXED(2, 15, 12, 32, 8);
+				else if (v == 'x') LAUNCH_FIXED(2, 15, 12, 16, 16);
+				else LAUNCH_FIXED(2, 15, 12, 32, 16);
+			}
+#undef LAUNCH_FIXED
+		}
+		if (!launched) hipLaunchKernelGGL(k_detect_fused, grid, dim3(256), (size_t)lds, ctx->stream, P);
+	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}

@@ -515,3 +515,32 @@ def test_orientation_degenerate_regimes(api, orc):
     ref.describe_points(pts, flat)
     _, rang, rwhite, rdesc = ref.fetch()
     assert np.array_equal(ang, rang) and np.array_equal(desc, rdesc) and np.all(desc == 0)
+
+
+@pytest.mark.parametrize("kind", ["l2", "hamming"])
+def test_sharded_association_single_process_ranks(api, orc, kind):
+    """SURVEY 8e on one GPU: R simulated ranks run phase 1 on their row slices, the column records are concatenated exactly as
+    all_gather_into_tensor would, and phase 2 must reproduce the slices of the unsharded result (the gloo test covers the collective)."""
+    import torch
+    from boofcv_amd import sharded
+    rng = np.random.default_rng(11)
+    ns, nd = 1000, 900
+    if kind == "l2":
+        src = _surf_like(rng, ns); dst = _surf_like(rng, nd)
+        dst[:500] = src[100:600] + rng.normal(scale=0.03, size=(500, 64)); src[900:950] = src[0:50]; dst[800:820] = dst[0:20]
+        full_p, full_f = orc.associate_l2(src, dst, api.Double_MAX_VALUE, True, threads=8)
+    else:
+        src = rng.integers(-2**31, 2**31, size=(ns, 16), dtype=np.int64).astype(np.int32)
+        dst = rng.integers(-2**31, 2**31, size=(nd, 16), dtype=np.int64).astype(np.int32)
+        dst[:400] = src[200:600]; dst[5] ^= 9; src[990] = src[250]
+        full_p, full_f = orc.associate_hamming(src, dst, api.Double_MAX_VALUE, True, threads=8)
+    eng = sharded.GpuEngine(device=0)
+    ts, td = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    for R in (1, 2, 3, 8):
+        part = sharded.row_partition(ns, R)
+        locals_ = [eng.phase1(kind, ts[b:b + c].contiguous(), b, td, api.Double_MAX_VALUE) for b, c in part]
+        col_all = torch.cat([l[2] for l in locals_])
+        for (b, c), (p, f, _) in zip(part, locals_):
+            p2, f2 = eng.phase2(col_all, R, nd, p.clone(), f.clone(), b)
+            torch.cuda.synchronize()
+            assert np.array_equal(p2.cpu().numpy(), full_p[b:b + c]) and np.array_equal(f2.cpu().numpy(), full_f[b:b + c]), (kind, R, b)
