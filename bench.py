@@ -195,7 +195,7 @@ def main():
             sample = frames[:args.cpu_frames].cpu().numpy()
             fps, dt, kps = cpu_baseline(sample, threads)
             cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-                   "sample": "%d of the same %dx%d frames, detect+describe+associate(next), %.1f s; key points/frame %s" % (len(sample), W, H, dt, kps)}
+                   "sample": "%d of the same %dx%d frames, detect+describe+associate(next frame), %.1f s of CPU work, %.0f key points/frame" % (len(sample), W, H, dt, float(np.mean(kps)))}
         line = {
             "metric": "1080p frames/sec detect+describe+associate", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,

@@ -749,7 +749,10 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 		}
 	}
 	{
-		ProfScope ps(ctx, "k_describe");
+		// per key point: every orientation and descriptor sample reads 12 integral-image taps; angle + descriptor + sign written once
+		const int gridWv = t.widthLargeGrid * t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
+		const double perKp = (double)(t.oriWidth * t.oriWidth + gridWv * gridWv) * 12 * 4 + 8.0 * t.dof + 8 + 1;
+		ProfScope ps(ctx, "k_describe", perKp * (double)total);
 		const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
 		const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
 		const dim3 grid((unsigned)blocks), block(256);
