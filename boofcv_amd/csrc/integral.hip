@@ -15,7 +15,8 @@
 #define TILE 64
 #define TPAD 65   // (row*65 + k) % 32 == (row + k) % 32: conflict-free column walks for ds_read/write_b32
 
-// one wave = one 64-row group; it sweeps the row left to right in 64-column tiles
+// one wave = one 64-row group; it sweeps the rows left to right in 64-column tiles.  Row -> (image, y) is tracked with wave-uniform
+// counters (no per-load division); the next tile's 64 row segments are loaded into registers while the current tile is scanned.
 __global__ __launch_bounds__(256) void k_integral_rows(ImgView in, ImgViewW out, long long totalRows) {
 	__shared__ float lds[4][TILE * TPAD];
 	const int wave = threadIdx.x >> 6;
@@ -24,25 +25,35 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgView in, ImgViewW out,
 	const long long row0 = ((long long)blockIdx.x * 4 + wave) * TILE;
 	if (row0 >= totalRows) return;
 	const int H = in.height, W = in.width;
-
-	// row pointers of the 64 rows this wave owns are recomputed on the fly: row -> (image, y)
-	const long long myRow = row0 + lane;
-	const bool myRowValid = myRow < totalRows;
+	const int nrows = (int)min((long long)TILE, totalRows - row0);
+	const long long img0 = row0 / H;
+	const int y0 = (int)(row0 - img0 * H);
+	const bool myRowValid = lane < nrows;
 	float carry = 0.0f;
 
+	float v[TILE];
+	// prologue: first tile
+	{
+		long long img = img0; int y = y0;
+#pragma unroll
+		for (int r = 0; r < TILE; r++) {
+			v[r] = (r < nrows && lane < W) ? in.data[img * in.imageStride + (long long)y * in.stride + lane] : 0.0f;
+			if (++y == H) { y = 0; img++; }
+		}
+	}
 	for (int c0 = 0; c0 < W; c0 += TILE) {
 		const int x = c0 + lane;
-		// load 64 rows x 64 columns, one row per instruction (coalesced), into the transposed-access tile
-#pragma unroll 8
-		for (int r = 0; r < TILE; r++) {
-			const long long row = row0 + r;
-			float v = 0.0f;
-			if (row < totalRows && x < W) {
-				const long long img = row / H;
-				const int y = (int)(row - img * H);
-				v = in.data[img * in.imageStride + (long long)y * in.stride + x];
+#pragma unroll
+		for (int r = 0; r < TILE; r++) tile[r * TPAD + lane] = v[r];
+		// issue the next tile's loads now; they complete under the scan below
+		if (c0 + TILE < W) {
+			const int xn = x + TILE;
+			long long img = img0; int y = y0;
+#pragma unroll
+			for (int r = 0; r < TILE; r++) {
+				v[r] = (r < nrows && xn < W) ? in.data[img * in.imageStride + (long long)y * in.stride + xn] : 0.0f;
+				if (++y == H) { y = 0; img++; }
 			}
-			tile[r * TPAD + lane] = v;
 		}
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -50,21 +61,32 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgView in, ImgViewW out,
 		if (myRowValid) {
 			float* mine = tile + lane * TPAD;
 			const int n = min(TILE, W - c0);
-#pragma unroll 8
-			for (int k = 0; k < n; k++) {
-				carry += mine[k];
-				mine[k] = carry;
+			if (n == TILE) {
+#pragma unroll
+				for (int k0 = 0; k0 < TILE; k0 += 16) {
+					float t[16];
+#pragma unroll
+					for (int k = 0; k < 16; k++) t[k] = mine[k0 + k];
+#pragma unroll
+					for (int k = 0; k < 16; k++) { carry += t[k]; t[k] = carry; }
+#pragma unroll
+					for (int k = 0; k < 16; k++) mine[k0 + k] = t[k];
+				}
+			} else {
+				for (int k = 0; k < n; k++) {
+					carry += mine[k];
+					mine[k] = carry;
+				}
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll 8
-		for (int r = 0; r < TILE; r++) {
-			const long long row = row0 + r;
-			if (row < totalRows && x < W) {
-				const long long img = row / H;
-				const int y = (int)(row - img * H);
-				out.data[img * out.imageStride + (long long)y * out.stride + x] = tile[r * TPAD + lane];
+		{
+			long long img = img0; int y = y0;
+#pragma unroll
+			for (int r = 0; r < TILE; r++) {
+				if (r < nrows && x < W) out.data[img * out.imageStride + (long long)y * out.stride + x] = tile[r * TPAD + lane];
+				if (++y == H) { y = 0; img++; }
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
