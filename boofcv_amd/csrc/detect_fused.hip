@@ -276,72 +276,95 @@ __device__ __forceinline__ float pblock_zero(const float* iiT, int X0, int Y0, i
 	return br - tr - bl + tl;
 }
 
+// the 32 taps of one inner pixel, reference order (hessianInner :183-201); c = patch row of yy, column slot of x
+template <class G, int L>
+__device__ __forceinline__ float fusedInnerDet(const float* c) {
+	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), rF = G::rF(L), rS = G::rS(L);
+	constexpr float norm = 1.0f / (float)(size * size);
+#define TAP(ro, co) c[G::tap((ro), (co))]
+	float Dxx, Dyy, Dxy;
+	{
+		constexpr int rt = -rS - 1, rb = rt + bLg, c0 = -rF - 1;
+		Dxx = TAP(rb, c0 + 3 * bS) - TAP(rt, c0 + 3 * bS) - TAP(rb, c0) + TAP(rt, c0);
+		Dxx -= 3 * (TAP(rb, c0 + 2 * bS) - TAP(rt, c0 + 2 * bS) - TAP(rb, c0 + bS) + TAP(rt, c0 + bS));
+	}
+	{
+		constexpr int r0 = -rF - 1, cl = -rS - 1, cr = cl + bLg;
+		Dyy = TAP(r0 + 3 * bS, cr) - TAP(r0 + 3 * bS, cl) - TAP(r0, cr) + TAP(r0, cl);
+		Dyy -= 3 * (TAP(r0 + 2 * bS, cr) - TAP(r0 + 2 * bS, cl) - TAP(r0 + bS, cr) + TAP(r0 + bS, cl));
+	}
+	{
+		constexpr int ry1 = -bS - 1, ry2 = ry1 + bS, ry3 = ry2 + 1, ry4 = ry3 + bS, c0 = -bS - 1;
+		constexpr int x3 = bS + 1, x4 = x3 + bS;
+		Dxy = TAP(ry2, c0 + bS) - TAP(ry1, c0 + bS) - TAP(ry2, c0) + TAP(ry1, c0);
+		Dxy -= TAP(ry2, c0 + x4) - TAP(ry1, c0 + x4) - TAP(ry2, c0 + x3) + TAP(ry1, c0 + x3);
+		Dxy += TAP(ry4, c0 + x4) - TAP(ry3, c0 + x4) - TAP(ry4, c0 + x3) + TAP(ry3, c0 + x3);
+		Dxy -= TAP(ry4, c0 + bS) - TAP(ry3, c0 + bS) - TAP(ry4, c0) + TAP(ry3, c0);
+	}
+#undef TAP
+	Dxx *= norm;
+	Dxy *= norm;
+	Dyy *= norm;
+	return Dxx * Dyy - 0.81f * Dxy * Dxy;
+}
+
 template <class G, int SKIP, int NL, int R, int L>
-__device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const float* __restrict__ d, const float* iiT, float* inten, int tid, int x0, int y0,
-												 int X0, int Y0) {
-	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), rF = G::rF(L), rS = G::rS(L), border = G::border(L);
+__device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const float* iiT, float* inten, int tid, int x0, int y0, int X0, int Y0) {
+	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), border = G::border(L);
 	constexpr float norm = 1.0f / (float)(size * size);
 	constexpr int pitch = G::IWp;
 	constexpr int r1 = bS / 2, r2 = bS + r1, r3 = bLg / 2, b = bS;
 	float* out = inten + L * G::ITH * G::ITp;
-	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
-#pragma unroll 1
-	for (int it = tid; it < G::ITH * G::ITW; it += 256) {
-		const int px = it & (G::ITW - 1), py = it / G::ITW;
-		const int x = x0 - R + px, y = y0 - R + py;
-		float det;
-		if (x < 0 || x >= P.w || y < 0 || y >= P.h) {
-			det = -INFINITY;
-		} else {
-			const int xx = x * SKIP, yy = y * SKIP;
-			float Dxx, Dyy, Dxy;
-			const bool inner = x >= border && x < P.w - border && y >= border && y < P.h - border;
-			if (inner) {
-				const float* c = iiT + (yy - Y0) * pitch + (x - x0 + R);   // base: patch row of yy, column slot of x
-#define TAP(ro, co) c[G::tap((ro), (co))]
-				{
-					constexpr int rt = -rS - 1, rb = rt + bLg, c0 = -rF - 1;
-					Dxx = TAP(rb, c0 + 3 * bS) - TAP(rt, c0 + 3 * bS) - TAP(rb, c0) + TAP(rt, c0);
-					Dxx -= 3 * (TAP(rb, c0 + 2 * bS) - TAP(rt, c0 + 2 * bS) - TAP(rb, c0 + bS) + TAP(rt, c0 + bS));
-				}
-				{
-					constexpr int r0 = -rF - 1, cl = -rS - 1, cr = cl + bLg;
-					Dyy = TAP(r0 + 3 * bS, cr) - TAP(r0 + 3 * bS, cl) - TAP(r0, cr) + TAP(r0, cl);
-					Dyy -= 3 * (TAP(r0 + 2 * bS, cr) - TAP(r0 + 2 * bS, cl) - TAP(r0 + bS, cr) + TAP(r0 + bS, cl));
-				}
-				{
-					constexpr int ry1 = -bS - 1, ry2 = ry1 + bS, ry3 = ry2 + 1, ry4 = ry3 + bS, c0 = -bS - 1;
-					constexpr int x3 = bS + 1, x4 = x3 + bS;
-					Dxy = TAP(ry2, c0 + bS) - TAP(ry1, c0 + bS) - TAP(ry2, c0) + TAP(ry1, c0);
-					Dxy -= TAP(ry2, c0 + x4) - TAP(ry1, c0 + x4) - TAP(ry2, c0 + x3) + TAP(ry1, c0 + x3);
-					Dxy += TAP(ry4, c0 + x4) - TAP(ry3, c0 + x4) - TAP(ry4, c0 + x3) + TAP(ry3, c0 + x3);
-					Dxy -= TAP(ry4, c0 + bS) - TAP(ry3, c0 + bS) - TAP(ry4, c0) + TAP(ry3, c0);
-				}
-#undef TAP
-			} else {
-				float ret = 0;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * 1.0f;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * -3.0f;
-				Dxx = ret;
-				ret = 0;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * 1.0f;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * -3.0f;
-				Dyy = ret;
-				ret = 0;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * 1.0f;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * -1.0f;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * 1.0f;
-				ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * -1.0f;
-				Dxy = ret;
-			}
-			Dxx *= norm;
-			Dxy *= norm;
-			Dyy *= norm;
-			det = Dxx * Dyy - 0.81f * Dxy * Dxy;
+	const int W = P.ii.width, H = P.ii.height;
+	// tile + halo entirely made of inner pixels of this level (true for all but the tiles along the image frame): no per-pixel tests
+	const bool interior = x0 - R >= border && x0 + G::TX + R <= P.w - border && y0 - R >= border && y0 + G::TY + R <= P.h - border;
+	if (interior) {
+		const int rowBase = (y0 - R) * SKIP - Y0;   // == rFmax + 1
+#pragma unroll 2
+		for (int it = tid; it < G::ITH * G::ITW; it += 256) {
+			const int px = it & (G::ITW - 1), py = it / G::ITW;
+			const float* c = iiT + (rowBase + py * SKIP) * pitch + px;
+			out[py * G::ITp + px] = fusedInnerDet<G, L>(c);
 		}
-		out[py * G::ITp + px] = det;
+	} else {
+#pragma unroll 1
+		for (int it = tid; it < G::ITH * G::ITW; it += 256) {
+			const int px = it & (G::ITW - 1), py = it / G::ITW;
+			const int x = x0 - R + px, y = y0 - R + py;
+			float det;
+			if (x < 0 || x >= P.w || y < 0 || y >= P.h) {
+				det = -INFINITY;   // outside the image: never >= anything, as if the neighbourhood were clamped
+			} else {
+				const int xx = x * SKIP, yy = y * SKIP;
+				const bool inner = x >= border && x < P.w - border && y >= border && y < P.h - border;
+				if (inner) {
+					det = fusedInnerDet<G, L>(iiT + (yy - Y0) * pitch + (x - x0 + R));
+				} else {
+					float Dxx, Dyy, Dxy;
+					float ret = 0;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * 1.0f;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * -3.0f;
+					Dxx = ret;
+					ret = 0;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * 1.0f;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * -3.0f;
+					Dyy = ret;
+					ret = 0;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * 1.0f;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * -1.0f;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * 1.0f;
+					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * -1.0f;
+					Dxy = ret;
+					Dxx *= norm;
+					Dxy *= norm;
+					Dyy *= norm;
+					det = Dxx * Dyy - 0.81f * Dxy * Dxy;
+				}
+			}
+			out[py * G::ITp + px] = det;
+		}
 	}
-	if constexpr (L + 1 < NL) fusedLevelFixed<G, SKIP, NL, R, L + 1>(P, d, iiT, inten, tid, x0, y0, X0, Y0);
+	if constexpr (L + 1 < NL) fusedLevelFixed<G, SKIP, NL, R, L + 1>(P, iiT, inten, tid, x0, y0, X0, Y0);
 }
 
 template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
@@ -398,7 +421,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		}
 	}
 	__syncthreads();
-	fusedLevelFixed<G, SKIP, NL, R, 0>(P, d, iiT, inten, tid, x0, y0, X0, Y0);
+	fusedLevelFixed<G, SKIP, NL, R, 0>(P, iiT, inten, tid, x0, y0, X0, Y0);
 	__syncthreads();
 
 	const int wave = tid >> 6, lane = tid & 63;

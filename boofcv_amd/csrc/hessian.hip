@@ -33,11 +33,15 @@ __device__ __forceinline__ float block_zero(const float* __restrict__ d, int str
 	y0 = min(y0, H - 1);
 	x1 = min(x1, W - 1);
 	y1 = min(y1, H - 1);
-	float br = 0, tr = 0, bl = 0, tl = 0;
-	if (x1 >= 0 && y1 >= 0) br = d[(long long)y1 * stride + x1];
-	if (y0 >= 0 && x1 >= 0) tr = d[(long long)y0 * stride + x1];
-	if (x0 >= 0 && y1 >= 0) bl = d[(long long)y1 * stride + x0];
-	if (x0 >= 0 && y0 >= 0) tl = d[(long long)y0 * stride + x0];
+	// branch-free: the four corners are always fetched (from coordinates clamped into the image) and zeroed afterwards, so the
+	// 40 taps of a border pixel are independent loads in flight together
+	const int cx0 = max(x0, 0), cy0 = max(y0, 0), cx1 = max(x1, 0), cy1 = max(y1, 0);
+	const float vbr = d[(long long)cy1 * stride + cx1], vtr = d[(long long)cy0 * stride + cx1];
+	const float vbl = d[(long long)cy1 * stride + cx0], vtl = d[(long long)cy0 * stride + cx0];
+	const float br = (x1 >= 0 && y1 >= 0) ? vbr : 0.0f;
+	const float tr = (y0 >= 0 && x1 >= 0) ? vtr : 0.0f;
+	const float bl = (x0 >= 0 && y1 >= 0) ? vbl : 0.0f;
+	const float tl = (x0 >= 0 && y0 >= 0) ? vtl : 0.0f;
 	return br - tr - bl + tl;
 }
 
