@@ -81,6 +81,12 @@ SIGNATURES = {
     "bhip_gaussian_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _d, _i, _fp, _i, _i]),
     "bhip_sobel_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _i, _i, _i]),
     "bhip_three_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _fp, _i, _i, _i]),
+    "bhip_conv_down_norm_h_f32": (_i, [_vp, _fp, _i, _fp, _i, _i, _i, _i, _fp, _i, _i, _i, _i, _i]),
+    "bhip_conv_down_norm_v_f32": (_i, [_vp, _fp, _i, _fp, _i, _i, _i, _i, _fp, _i, _i, _i, _i, _i]),
+    "bhip_gaussian_kernel1d_f32": (_i, [_d, _i, _fp, _i]),
+    "bhip_pyramid_layout": (_i, [_i, _i, _ip, _i, _ip, _llp, _llp]),
+    "bhip_pyramid_f32": (_i, [_vp, _fp, _i, _ip, _i, _fp, _i, _i, _i, _i, _fp]),
+    "bhip_pyramid_dev_f32": (_i, [_vp, _fp, _i, _ip, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
     "bhip_brief_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _dp, _i, _i32p]),
 }
 

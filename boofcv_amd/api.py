@@ -58,6 +58,10 @@ class Context:
     def synchronize(self):
         _check(self, _lib.load().bhip_ctx_synchronize(self._h))
 
+    def lastError(self):
+        msg = _lib.load().bhip_last_error(self._h)
+        return msg.decode(errors="replace") if msg else ""
+
     def profile(self, on=True):
         """Bracket every kernel launch with HIP events on this context's stream."""
         _check(self, _lib.load().bhip_profile_enable(self._h, 1 if on else 0))
@@ -714,6 +718,112 @@ class ConvolveImageNormalized:
     @staticmethod
     def vertical(kernel, src, dst, ctx=None):
         _conv(_lib.load().bhip_conv_norm_v_f32, kernel, src, dst, ctx)
+
+
+class FactoryKernelGaussian:
+    @staticmethod
+    def gaussian1D_F32(sigma, radius):
+        """FactoryKernelGaussian.gaussian(Kernel1D_F32.class, sigma, radius) (I:factory/filter/kernel/FactoryKernelGaussian.java:120-153)"""
+        if sigma <= 0 and radius <= 0:
+            raise IllegalArgumentException("Sigma must be > 0")
+        L = _lib.load()
+        w = -L.bhip_gaussian_kernel1d_f32(float(sigma), int(radius), None, 0)
+        out = np.zeros(w, dtype=np.float32)
+        L.bhip_gaussian_kernel1d_f32(float(sigma), int(radius), out.ctypes.data_as(_lib._fp), w)
+        return Kernel1D_F32(out)
+
+
+class ConvolveImageDownNormalized:
+    """I:alg/filter/convolve/ConvolveImageDownNormalized.java:53-86 (the NORMALIZED ConvolveDown of the discrete pyramid)"""
+
+    @staticmethod
+    def _run(fn, kernel, image, dest, skip, ctx):
+        ctx = _ctx(ctx)
+        rc = fn(ctx._h, kernel.data.ctypes.data_as(_lib._fp), kernel.width, image._p(), image.startIndex, image.stride, image.width, image.height,
+                dest._p(), dest.startIndex, dest.stride, dest.width, dest.height, int(skip))
+        _check(ctx, rc)
+
+    @staticmethod
+    def horizontal(kernel, image, dest, skip, ctx=None):
+        ConvolveImageDownNormalized._run(_lib.load().bhip_conv_down_norm_h_f32, kernel, image, dest, skip, ctx)
+
+    @staticmethod
+    def vertical(kernel, image, dest, skip, ctx=None):
+        ConvolveImageDownNormalized._run(_lib.load().bhip_conv_down_norm_v_f32, kernel, image, dest, skip, ctx)
+
+
+class PyramidDiscreteSampleBlur:
+    """I:alg/transform/pyramid/PyramidDiscreteSampleBlur.java:48-126: layer i = layer i-1 blurred with the (border-normalised) kernel and
+    sub-sampled by scale[i]/scale[i-1]; layer 0 = the input when scale[0] == 1."""
+
+    def __init__(self, kernel, sigma, saveOriginalReference, scaleFactors, ctx=None):
+        self.ctx = _ctx(ctx)
+        self.kernel = kernel
+        self.saveOriginalReference = bool(saveOriginalReference)
+        self.scale = [int(s) for s in scaleFactors]
+        # ImagePyramidBase.checkScales (T:struct/pyramid/ImagePyramidBase.java:100-112)
+        if self.scale[0] < 0:
+            raise IllegalArgumentException("The first layer must be more than zero.")
+        for a, b in zip(self.scale, self.scale[1:]):
+            if b < a:
+                raise IllegalArgumentException("Higher layers must be the same size or larger than previous layers.")
+        self.sigmas = [0.0] * len(self.scale)
+        for i in range(1, len(self.scale)):
+            prev, applied = self.sigmas[i - 1], sigma * self.scale[i - 1]
+            self.sigmas[i] = math.sqrt(prev * prev + applied * applied)
+        self.layers = None
+
+    def getNumLayers(self):
+        return len(self.scale)
+
+    def getScale(self, layer):
+        return float(self.scale[layer])
+
+    def getSigma(self, layer):
+        return self.sigmas[layer]
+
+    def getSampleOffset(self, layer):
+        return 0.0
+
+    def process(self, input):
+        L = _lib.load()
+        n = len(self.scale)
+        sc = np.asarray(self.scale, dtype=np.int32)
+        dims = np.zeros(2 * n, dtype=np.int32)
+        offs = np.zeros(n, dtype=np.int64)
+        total = C.c_longlong(0)
+        if L.bhip_pyramid_layout(input.width, input.height, sc.ctypes.data_as(_lib._ip), n, dims.ctypes.data_as(_lib._ip),
+                                 offs.ctypes.data_as(_lib._llp), C.byref(total)) != 0:
+            raise IllegalArgumentException("bad pyramid scales")
+        packed = np.zeros(total.value, dtype=np.float32)
+        rc = L.bhip_pyramid_f32(self.ctx._h, self.kernel.data.ctypes.data_as(_lib._fp), self.kernel.width, sc.ctypes.data_as(_lib._ip), n, input._p(),
+                                input.startIndex, input.stride, input.width, input.height, packed.ctypes.data_as(_lib._fp))
+        _check(self.ctx, rc)
+        self.layers = []
+        for i in range(n):
+            w, h = int(dims[2 * i]), int(dims[2 * i + 1])
+            if i == 0 and self.scale[0] == 1 and self.saveOriginalReference:
+                self.layers.append(input)  # setFirstLayer(input)
+            else:
+                self.layers.append(GrayF32(w, h, packed[offs[i]:offs[i] + w * h]))
+        return self
+
+    def getLayer(self, i):
+        return self.layers[i]
+
+    def getWidth(self, i):
+        return self.layers[i].width
+
+    def getHeight(self, i):
+        return self.layers[i].height
+
+
+class FactoryPyramid:
+    @staticmethod
+    def discreteGaussian(scaleFactors, sigma, radius, saveOriginalReference=False, ctx=None):
+        """I:factory/transform/pyramid/FactoryPyramid.java:53-61"""
+        kernel = FactoryKernelGaussian.gaussian1D_F32(sigma, radius)
+        return PyramidDiscreteSampleBlur(kernel, sigma, saveOriginalReference, scaleFactors, ctx)
 
 
 class BlurImageOps:

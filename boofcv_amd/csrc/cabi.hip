@@ -17,6 +17,8 @@ int bhip_assoc_phase2(bhip_ctx* ctx, const void* colAll, int nranks, int nd, int
 int bhip_assoc_coltop_size();
 int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
 					 int height, float* out, int outStride);
+int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
+						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch);
 int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out);
@@ -798,6 +800,130 @@ int bhip_gaussian_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride,
 	BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, sc->a.as<float>(), width, width, height, sc->b.as<float>(), width));
 	BHIP_TRY(bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->b.as<float>(), width, width, height, sc->c.as<float>(), width));
 	return downloadImage(ctx, sc->c.p, out, outStart, outStride, width, height);
+}
+
+static int convDownHost(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, int inStart, int inStride, int width, int height,
+						float* out, int outStart, int outStride, int outWidth, int outHeight, int skip) {
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, outWidth, outHeight);
+	if (!kernel) return bhip_fail(ctx, BHIP_ERR_INVALID, "null kernel");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	// pixels the reference does not write keep the caller's values
+	BHIP_TRY(uploadImage(ctx, sc->b, out, outStart, outStride, outWidth, outHeight));
+	BHIP_TRY(bhip_launch_conv_down(ctx, vertical, kernel, kw, sc->a.as<float>(), 0, width, width, height, sc->b.as<float>(), 0, outWidth, outWidth,
+								   outHeight, skip, 1));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, outWidth, outHeight);
+}
+int bhip_conv_down_norm_h_f32(bhip_ctx* ctx, const float* kernel, int kw, const float* in, int inStart, int inStride, int width, int height, float* out,
+							  int outStart, int outStride, int outWidth, int outHeight, int skip) {
+	CHECK_CTX(ctx);
+	return convDownHost(ctx, false, kernel, kw, in, inStart, inStride, width, height, out, outStart, outStride, outWidth, outHeight, skip);
+}
+int bhip_conv_down_norm_v_f32(bhip_ctx* ctx, const float* kernel, int kw, const float* in, int inStart, int inStride, int width, int height, float* out,
+							  int outStart, int outStride, int outWidth, int outHeight, int skip) {
+	CHECK_CTX(ctx);
+	return convDownHost(ctx, true, kernel, kw, in, inStart, inStride, width, height, out, outStart, outStride, outWidth, outHeight, skip);
+}
+
+// FactoryKernelGaussian.gaussian(Kernel1D_F32.class, sigma, radius) (I:factory/filter/kernel/FactoryKernelGaussian.java:120-153)
+int bhip_gaussian_kernel1d_f32(double sigma, int radius, float* out, int capacity) {
+	if (sigma <= 0 && radius <= 0) return -1;
+	std::vector<float> k = bhip_gaussian1d_f32(sigma, radius);
+	if (!out || (int)k.size() > capacity) return -(int)k.size();
+	for (size_t i = 0; i < k.size(); i++) out[i] = k[i];
+	return (int)k.size();
+}
+
+// PyramidDiscreteSampleBlur: layer geometry (ImagePyramidBase.initialize) + scale checks (ImagePyramidBase.checkScales)
+int bhip_pyramid_layout(int width, int height, const int* scales, int n, int* dims, long long* offsets, long long* totalFloats) {
+	if (width <= 0 || height <= 0 || !scales || n <= 0) return BHIP_ERR_INVALID;
+	if (scales[0] <= 0) return BHIP_ERR_INVALID;
+	int prev = 0;
+	long long off = 0;
+	for (int i = 0; i < n; i++) {
+		if (scales[i] < prev) return BHIP_ERR_INVALID;
+		prev = scales[i];
+		const double sf = scales[i];
+		int w = (int)std::ceil(width / sf), h = (int)std::ceil(height / sf);
+		if (i == 0 && scales[0] == 1) { w = width; h = height; }
+		if (dims) { dims[2 * i] = w; dims[2 * i + 1] = h; }
+		if (offsets) offsets[i] = off;
+		off += (long long)w * h;
+	}
+	if (totalFloats) *totalFloats = off;
+	return BHIP_OK;
+}
+
+int bhip_pyramid_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, const int* scales, int n, const float* dev_in, long long inImageStride, int inStride,
+						 int width, int height, int batch, float* dev_out) {
+	CHECK_CTX(ctx);
+	if (!kernel || !dev_in || !dev_out || batch <= 0 || inStride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad pyramid arguments");
+	if (n > 32) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "more than 32 layers");
+	int dims[64];
+	long long offs[32], total = 0;
+	if (bhip_pyramid_layout(width, height, scales, n, dims, offs, &total) != BHIP_OK) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad pyramid scales");
+	for (int i = 1; i < n; i++)
+		if (scales[i] / scales[i - 1] <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Skip must be >= 1");
+	CtxScratch* sc = scratchOf(ctx);
+	// freshly created layers are zero (pixels outside floor(prev/skip) are never written)
+	BHIP_HIP(ctx, hipMemsetAsync(dev_out, 0, (size_t)total * batch * 4, ctx->stream));
+	// `temp` of the reference is one grow-only image shared by all layers: zero when first allocated, afterwards it keeps the
+	// previous layer's values wherever the off-grid skip>=3 case leaves a column unwritten.  Same here: one dense region per
+	// frame, sized for the first convolved layer, cleared once per call (= first process() of a fresh pyramid object).
+	long long tempCap = 0;
+	{
+		int pw0 = width, ph0 = height;
+		for (int i = 0; i < n; i++) {
+			if (!(i == 0 && scales[0] == 1)) {
+				const int skip = i == 0 ? scales[0] : scales[i] / scales[i - 1];
+				tempCap = std::max(tempCap, (long long)(pw0 / skip) * ph0);
+			}
+			pw0 = dims[2 * i]; ph0 = dims[2 * i + 1];
+		}
+	}
+	if (tempCap > 0) {
+		BHIP_TRY(sc->d.reserve(ctx, (size_t)tempCap * 4 * batch));
+		BHIP_HIP(ctx, hipMemsetAsync(sc->d.p, 0, (size_t)tempCap * 4 * batch, ctx->stream));
+	}
+	const float* prev = dev_in;
+	long long prevImageStride = inImageStride;
+	int prevStride = inStride, pw = width, ph = height;
+	for (int i = 0; i < n; i++) {
+		float* layer = dev_out + offs[i];
+		const int lw = dims[2 * i], lh = dims[2 * i + 1];
+		if (i == 0 && scales[0] == 1) {
+			ProfScope prof(ctx, "pyramid_copy", 8.0 * width * height * batch);
+			for (int b = 0; b < batch; b++)
+				BHIP_HIP(ctx, hipMemcpy2DAsync(layer + (long long)b * total, (size_t)lw * 4, dev_in + (long long)b * inImageStride, (size_t)inStride * 4,
+											   (size_t)width * 4, (size_t)height, hipMemcpyDeviceToDevice, ctx->stream));
+		} else {
+			const int skip = i == 0 ? scales[0] : scales[i] / scales[i - 1];
+			const int tw = pw / skip;
+			if (tw <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "pyramid layer collapses to zero width");
+			BHIP_TRY(bhip_launch_conv_down(ctx, false, kernel, kw, prev, prevImageStride, prevStride, pw, ph, sc->d.as<float>(), tempCap, tw, tw, ph, skip,
+										   batch));
+			BHIP_TRY(bhip_launch_conv_down(ctx, true, kernel, kw, sc->d.as<float>(), tempCap, tw, tw, ph, layer, total, lw, lw, lh, skip, batch));
+		}
+		prev = layer; prevImageStride = total; prevStride = lw; pw = lw; ph = lh;
+	}
+	return BHIP_OK;
+}
+
+int bhip_pyramid_f32(bhip_ctx* ctx, const float* kernel, int kw, const int* scales, int n, const float* in, int inStart, int inStride, int width,
+					 int height, float* out) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, in, inStride, width, height);
+	if (!out || !kernel || !scales) return bhip_fail(ctx, BHIP_ERR_INVALID, "null buffer");
+	long long total = 0;
+	if (bhip_pyramid_layout(width, height, scales, n, nullptr, nullptr, &total) != BHIP_OK) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad pyramid scales");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)total * 4));
+	BHIP_TRY(bhip_pyramid_dev_f32(ctx, kernel, kw, scales, n, sc->a.as<float>(), (long long)width * height, width, width, height, 1, sc->b.as<float>()));
+	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->b.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
 }
 
 static int gradHost(bhip_ctx* ctx, int kind, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,

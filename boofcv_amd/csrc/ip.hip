@@ -100,6 +100,140 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 	return BHIP_OK;
 }
 
+// ---------------- down-sampling convolution (pyramid layer step) ----------------
+// ConvolveImageDownNormalized.horizontal/vertical   I:alg/filter/convolve/ConvolveImageDownNormalized.java:53-86
+//   interior  I:alg/filter/convolve/down/ConvolveDownNoBorderUnrolled_F32_F32.java:140-154,351-366 (widths 3..11, first tap assigns)
+//             I:alg/filter/convolve/down/ConvolveDownNoBorderStandard.java:43-110 (total = 0 first)
+//   border    I:alg/filter/convolve/down/ConvolveDownNormalized_JustBorder.java:43-139
+//   naive     I:alg/filter/convolve/down/ConvolveDownNormalizedNaive.java:40-94 (kernel.width >= image.width)
+//   ranges    I:alg/filter/convolve/down/UtilDownConvolve.java:27-44
+// The reference runs interior, then left border, then right border; a later loop overwrites an earlier one.  Per output index D
+// along the filtered axis that order collapses to: right border if D*skip in [offsetEnd, sideTrunc); else left border if
+// D*skip < offset; else interior centred on D*skip + offset%skip while that is <= maxSide; else the pixel is not written.
+// (offset%skip != 0 only for skip >= 3 with radius > skip: the reference then samples off-grid and leaves one column untouched;
+// reproduced as is.)
+struct ConvDownParams {
+	const float* in;
+	float* out;
+	long long inImageStride, outImageStride;
+	int inStride, outStride, width, height;   // input size
+	int skip, kw, radius;
+	int unrolled, naive;
+	int offset, offsetRem, maxSide, offsetEnd, sideTrunc;   // along the filtered axis
+	float k[BHIP_MAX_TAPS];
+};
+
+template <bool VERTICAL>
+__global__ __launch_bounds__(256) void k_conv_down(ConvDownParams P) {
+	const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+	const int oy = blockIdx.y;
+	const int outW = VERTICAL ? P.width : P.width / P.skip;
+	if (ox >= outW) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	const int D = VERTICAL ? oy : ox;
+	const int side = VERTICAL ? P.height : P.width;
+	const long long step = VERTICAL ? P.inStride : 1;
+	const int r = P.radius;
+	int centre = D * P.skip;
+	int k0, k1;   // tap range [k0,k1] relative to the centre
+	bool normalise = true;
+	if (P.naive) {
+		k0 = max(-r, -centre);
+		k1 = min(r, side - 1 - centre);
+	} else if (centre >= P.offsetEnd && centre < P.sideTrunc) {
+		k0 = -r;
+		k1 = min(r, side - centre - 1);
+	} else if (centre < P.offset) {
+		k0 = -centre;
+		k1 = r;
+	} else {
+		centre += P.offsetRem;
+		if (centre > P.maxSide) return;
+		k0 = -r; k1 = r;
+		normalise = false;
+	}
+	const float* src = VERTICAL ? img + (long long)centre * P.inStride + ox : img + (long long)oy * P.inStride + centre;
+	float result;
+	if (normalise) {
+		float total = 0, weight = 0;
+		for (int k = k0; k <= k1; k++) {
+			const float w = P.k[k + r];
+			weight += w;
+			total += src[k * step] * w;
+		}
+		result = total / weight;
+	} else {
+		const float* s0 = src - r * step;
+		float total;
+		if (P.unrolled) {
+			total = s0[0] * P.k[0];
+			for (int k = 1; k < P.kw; k++) total += s0[k * step] * P.k[k];
+		} else {
+			total = 0;
+			for (int k = 0; k < P.kw; k++) total += s0[k * step] * P.k[k];
+		}
+		result = total;
+	}
+	P.out[(long long)blockIdx.z * P.outImageStride + (long long)oy * P.outStride + ox] = result;
+}
+
+static int downMaxSide(int sideLength, int skip, int radius) {
+	int ret = sideLength - (sideLength % skip);
+	if (ret + radius >= sideLength) {
+		ret = sideLength - radius - 1;
+		ret = ret - (ret % skip);
+	} else {
+		ret -= skip;
+	}
+	return ret;
+}
+static int downOffset(int skip, int radius) { return radius <= skip ? skip : radius + radius % skip; }
+
+int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
+						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch) {
+	if (kw <= 0 || kw > BHIP_MAX_TAPS) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "kernel width not supported");
+	// ConvolveImageDownNoBorder.checkParameters* (I:alg/filter/convolve/ConvolveImageDownNoBorder.java:160-186)
+	if (skip <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Skip must be >= 1");
+	if (outWidth < width / skip) return bhip_fail(ctx, BHIP_ERR_INVALID, "Output width is too small");
+	if (outHeight < height / skip) return bhip_fail(ctx, BHIP_ERR_INVALID, "Output height is too small");
+	// checkParametersH/V on the no-border path; on the naive path GrayF32.set would throw ImageAccessException for the same shapes
+	if (vertical && outWidth < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "Output width is too small");
+	if (!vertical && outHeight < height) return bhip_fail(ctx, BHIP_ERR_INVALID, "Output height is too small");
+	ConvDownParams P;
+	P.in = in; P.out = out; P.inImageStride = inImageStride; P.outImageStride = outImageStride; P.inStride = inStride; P.outStride = outStride;
+	P.width = width; P.height = height; P.skip = skip; P.kw = kw; P.radius = kw / 2;
+	for (int i = 0; i < kw; i++) P.k[i] = kernel[i];
+	const int r = P.radius;
+	const int side = vertical ? height : width;
+	P.naive = kw >= width ? 1 : 0;   // sic: the vertical form tests the image WIDTH as well
+	P.unrolled = (kw % 2 == 1 && (kw == 3 || kw == 5 || kw == 7 || kw == 9 || kw == 11)) ? 1 : 0;
+	P.offset = downOffset(skip, r);
+	P.offsetRem = P.offset % skip;
+	P.maxSide = downMaxSide(side, skip, r);
+	P.offsetEnd = P.maxSide + skip;
+	P.sideTrunc = side - side % skip;
+	if (!P.naive) {
+		if (kw % 2 != 1) return bhip_fail(ctx, BHIP_ERR_INVALID, "Non symmetric odd kernels not supported");
+		// every loop of the reference must stay inside the image along the filtered axis (Java would throw
+		// ArrayIndexOutOfBounds or silently read the neighbouring row)
+		bool ok = true;
+		if (P.offset <= P.maxSide) ok = ok && P.offset - r >= 0;
+		int lastLeft = ((P.offset - 1) / skip) * skip;                        // largest multiple of skip below offset
+		ok = ok && lastLeft + r < side;
+		if (P.offsetEnd < P.sideTrunc) ok = ok && P.offsetEnd - r >= 0;
+		if (!ok) return bhip_fail(ctx, BHIP_ERR_INVALID, "kernel does not fit the image along the filtered axis");
+	}
+	const int gw = vertical ? width : width / skip;
+	const int gh = vertical ? height / skip : height;
+	if (gw <= 0 || gh <= 0 || batch <= 0) return BHIP_OK;
+	ProfScope prof(ctx, vertical ? "k_conv_down_v" : "k_conv_down_h", 4.0 * batch * ((double)width * height + (double)gw * gh));
+	dim3 grid((gw + 255) / 256, gh, batch);
+	if (vertical) hipLaunchKernelGGL(k_conv_down<true>, grid, dim3(256), 0, ctx->stream, P);
+	else hipLaunchKernelGGL(k_conv_down<false>, grid, dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
 // ---------------- gradients ----------------
 struct GradParams {
 	const float* in;

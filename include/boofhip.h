@@ -198,6 +198,29 @@ int bhip_sobel_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, in
 /* GradientThree.process(GrayF32,...) -> GradientThree_Standard.process (I:alg/filter/derivative/impl/GradientThree_Standard.java:40-62) */
 int bhip_three_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,
 				   int outStride, int border);
+/* ConvolveImageDownNormalized.horizontal/vertical (I:alg/filter/convolve/ConvolveImageDownNormalized.java:53-86): every skip-th pixel
+ * along the filtered axis, kernel re-normalised where it overlaps the border (ConvolveDownNormalized_JustBorder.java:43-139), plain
+ * sum inside (ConvolveDownNoBorderUnrolled_F32_F32 / ConvolveDownNoBorderStandard), naive form when kernelWidth >= width.  `out` is
+ * outWidth x outHeight and must satisfy ConvolveImageDownNoBorder.checkParametersH/V (:160-176); pixels the reference does not write
+ * keep the caller's values.  BHIP_ERR_INVALID where the reference throws. */
+int bhip_conv_down_norm_h_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, const float* in, int inStart, int inStride, int width, int height,
+							  float* out, int outStart, int outStride, int outWidth, int outHeight, int skip);
+int bhip_conv_down_norm_v_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, const float* in, int inStart, int inStride, int width, int height,
+							  float* out, int outStart, int outStride, int outWidth, int outHeight, int skip);
+/* PyramidDiscreteSampleBlur (I:alg/transform/pyramid/PyramidDiscreteSampleBlur.java:68-126).  bhip_pyramid_layout is
+ * ImagePyramidBase.initialize + checkScales (T:struct/pyramid/ImagePyramidBase.java:73-112): dims[2i],dims[2i+1] = width,height of layer i,
+ * offsets[i] = first float of layer i in the packed output (layers dense, stride = layer width), *totalFloats = floats per frame.
+ * bhip_pyramid_f32 = process(input) for one host image; bhip_pyramid_dev_f32 runs `batch` device-resident frames (frame b of the
+ * output starts at dev_out + b * totalFloats) without leaving the stream.  The 1-D kernel is FactoryPyramid.discreteGaussian's
+ * FactoryKernelGaussian.gaussian(Kernel1D_F32, sigma, radius) (I:factory/transform/pyramid/FactoryPyramid.java:53-61), built by the caller. */
+/* FactoryKernelGaussian.gaussian(Kernel1D_F32.class, sigma, radius) (I:factory/filter/kernel/FactoryKernelGaussian.java:120-153): host-only
+ * helper for callers outside the JVM.  Returns the kernel width, or -(needed width) when capacity is too small / out is NULL. */
+int bhip_gaussian_kernel1d_f32(double sigma, int radius, float* out, int capacity);
+int bhip_pyramid_layout(int width, int height, const int* scales, int numLayers, int* dims, long long* offsets, long long* totalFloats);
+int bhip_pyramid_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, const int* scales, int numLayers, const float* in, int inStart,
+					 int inStride, int width, int height, float* out);
+int bhip_pyramid_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, const int* scales, int numLayers, const float* dev_in,
+						 long long inImageStride, int inStride, int width, int height, int batch, float* dev_out);
 /* DescribePointBrief.process for n points on one image (F:alg/feature/describe/DescribePointBrief.java:73-89;
  * F:alg/feature/describe/impl/ImplDescribeBinaryCompare_F32.java:47-101).  The definition (samplePoints[numPoints][2], compare[numPoints][2])
  * is supplied by the caller: FactoryBriefDefinition.gaussian2 depends on java.util.Random + StrictMath and is generated on the Java side. */

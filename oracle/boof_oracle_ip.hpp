@@ -281,6 +281,274 @@ inline void pyramidSubsample(const GrayF32& in, GrayF32& out, int skip) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Down-sampling convolution with a re-normalised border  (pyramid layer step)
+//   I:alg/filter/convolve/ConvolveImageDownNormalized.java:53-86  (dispatch: naive when kernel.width >= image.width,
+//     for BOTH directions -- the vertical form also tests image.width; else no-border interior, then just-border)
+//   I:alg/filter/convolve/down/UtilDownConvolve.java:27-44
+// ------------------------------------------------------------------------------------------------
+inline int downComputeMaxSide(int sideLength, int skip, int radius) {
+	int ret = sideLength - (sideLength % skip);
+	if (ret + radius >= sideLength) {
+		ret = sideLength - radius - 1;
+		ret = ret - (ret % skip);
+	} else {
+		ret -= skip;
+	}
+	return ret;
+}
+inline int downComputeOffset(int skip, int radius) { return radius <= skip ? skip : radius + radius % skip; }
+
+struct DownConvError : std::runtime_error { using std::runtime_error::runtime_error; };
+// bounds-checked read standing in for Java's array check (Java throws ArrayIndexOutOfBounds when a loop
+// leaves the backing array; leaving only the ROW would read a neighbouring row -- both are flagged here,
+// the product returns BHIP_ERR_INVALID for the same shapes)
+inline float downRead(const GrayF32& im, int x, int y) {
+	if (x < 0 || y < 0 || x >= im.width || y >= im.height) throw DownConvError("down-convolution reads outside the image");
+	return im.data[im.startIndex + y * im.stride + x];
+}
+// I:alg/filter/convolve/ConvolveImageDownNoBorder.java:160-176
+inline void downCheckH(const GrayF32& in, const GrayF32& out, int skip) {
+	if (skip <= 0) throw DownConvError("Skip must be >= 1");
+	if (out.width < in.width / skip) throw DownConvError("Output width is too small");
+	if (out.height < in.height) throw DownConvError("Output height is too small");
+}
+inline void downCheckV(const GrayF32& in, const GrayF32& out, int skip) {
+	if (skip <= 0) throw DownConvError("Skip must be >= 1");
+	if (out.width < in.width) throw DownConvError("Output width is too small");
+	if (out.height < in.height / skip) throw DownConvError("Output height is too small");
+}
+// ConvolveImageDownNormalized.checkParameters == ConvolveImageDownNoBorder.checkParameters (:178-186)
+inline void downCheck(const GrayF32& in, const GrayF32& out, int skip) {
+	if (skip <= 0) throw DownConvError("Skip must be >= 1");
+	if (out.width < in.width / skip) throw DownConvError("Output width is too small");
+	if (out.height < in.height / skip) throw DownConvError("Output height is too small");
+}
+// interior: unrolled widths 3..11 assign the first tap (ConvolveDownNoBorderUnrolled_F32_F32.java:140-154, 351-366),
+// every other width starts from 0 (ConvolveDownNoBorderStandard.java:43-77, 79-110)
+inline void downNoBorderHorizontal(const float* ker, int kw, const GrayF32& input, GrayF32& output, int skip) {
+	if (kw % 2 != 1) throw DownConvError("Non symmetric odd kernels not supported");
+	const int radius = kw / 2;
+	const bool unrolled = convIsUnrolled(kw, radius);
+	const int widthEnd = downComputeMaxSide(input.width, skip, radius);
+	const int offsetX = downComputeOffset(skip, radius);
+	for (int i = 0; i < input.height; i++) {
+		int dstX = offsetX / skip;
+		for (int x = offsetX; x <= widthEnd; x += skip) {
+			float total;
+			if (unrolled) {
+				total = downRead(input, x - radius, i) * ker[0];
+				for (int k = 1; k < kw; k++) total += downRead(input, x - radius + k, i) * ker[k];
+			} else {
+				total = 0;
+				for (int k = 0; k < kw; k++) total += downRead(input, x - radius + k, i) * ker[k];
+			}
+			output.set(dstX++, i, total);
+		}
+	}
+}
+inline void downNoBorderVertical(const float* ker, int kw, const GrayF32& input, GrayF32& output, int skip) {
+	if (kw % 2 != 1) throw DownConvError("Non symmetric odd kernels not supported");
+	const int radius = kw / 2;
+	const bool unrolled = convIsUnrolled(kw, radius);
+	const int heightEnd = downComputeMaxSide(input.height, skip, radius);
+	const int offsetY = downComputeOffset(skip, radius);
+	for (int y = offsetY; y <= heightEnd; y += skip) {
+		for (int x = 0; x < input.width; x++) {
+			float total;
+			if (unrolled) {
+				total = downRead(input, x, y - radius) * ker[0];
+				for (int k = 1; k < kw; k++) total += downRead(input, x, y - radius + k) * ker[k];
+			} else {
+				total = 0;
+				for (int k = 0; k < kw; k++) total += downRead(input, x, y - radius + k) * ker[k];
+			}
+			output.set(x, y / skip, total);
+		}
+	}
+}
+// I:alg/filter/convolve/down/ConvolveDownNormalized_JustBorder.java:43-90
+inline void downJustBorderHorizontal(const float* ker, int kw, const GrayF32& input, GrayF32& output, int skip) {
+	const int radius = kw / 2;
+	const int offset = downComputeOffset(skip, radius);
+	const int offsetEnd = downComputeMaxSide(input.width, skip, radius) + skip;
+	const int width = input.width - input.width % skip;
+	for (int y = 0; y < input.height; y++) {
+		int dstX = 0;
+		for (int x = 0; x < offset; x += skip) {
+			float total = 0, weight = 0;
+			for (int k = -x; k <= radius; k++) {
+				float w = ker[k + radius];
+				weight += w;
+				total += downRead(input, x + k, y) * w;
+			}
+			output.set(dstX++, y, total / weight);
+		}
+		dstX = offsetEnd / skip;
+		for (int x = offsetEnd; x < width; x += skip) {
+			float total = 0, weight = 0;
+			int endKernel = input.width - x - 1;
+			if (endKernel > radius) endKernel = radius;
+			for (int k = -radius; k <= endKernel; k++) {
+				float w = ker[k + radius];
+				weight += w;
+				total += downRead(input, x + k, y) * w;
+			}
+			output.set(dstX++, y, total / weight);
+		}
+	}
+}
+// :92-139
+inline void downJustBorderVertical(const float* ker, int kw, const GrayF32& input, GrayF32& output, int skip) {
+	const int radius = kw / 2;
+	const int offset = downComputeOffset(skip, radius);
+	const int offsetEnd = downComputeMaxSide(input.height, skip, radius) + skip;
+	const int width = input.width;
+	const int height = input.height - input.height % skip;
+	for (int y = 0; y < offset; y += skip) {
+		for (int x = 0; x < width; x++) {
+			float total = 0, weight = 0;
+			for (int k = -y; k <= radius; k++) {
+				float w = ker[k + radius];
+				weight += w;
+				total += downRead(input, x, y + k) * w;
+			}
+			output.set(x, y / skip, total / weight);
+		}
+	}
+	for (int y = offsetEnd; y < height; y += skip) {
+		int endKernel = input.height - y - 1;
+		if (endKernel > radius) endKernel = radius;
+		for (int x = 0; x < width; x++) {
+			float total = 0, weight = 0;
+			for (int k = -radius; k <= endKernel; k++) {
+				float w = ker[k + radius];
+				weight += w;
+				total += downRead(input, x, y + k) * w;
+			}
+			output.set(x, y / skip, total / weight);
+		}
+	}
+}
+// I:alg/filter/convolve/down/ConvolveDownNormalizedNaive.java:40-94
+inline void downNaiveHorizontal(const float* ker, int kw, const GrayF32& input, GrayF32& output, int skip) {
+	const int radius = kw / 2;
+	const int width = input.width - input.width % skip;
+	for (int y = 0; y < input.height; y++)
+		for (int x = 0; x < width; x += skip) {
+			float total = 0, div = 0;
+			int startX = x - radius, endX = x + radius;
+			if (startX < 0) startX = 0;
+			if (endX >= input.width) endX = input.width - 1;
+			for (int j = startX; j <= endX; j++) {
+				float v = ker[j - x + radius];
+				total += input.get(j, y) * v;
+				div += v;
+			}
+			output.set(x / skip, y, total / div);
+		}
+}
+inline void downNaiveVertical(const float* ker, int kw, const GrayF32& input, GrayF32& output, int skip) {
+	const int radius = kw / 2;
+	const int height = input.height - input.height % skip;
+	for (int y = 0; y < height; y += skip)
+		for (int x = 0; x < input.width; x++) {
+			float total = 0, div = 0;
+			int startY = y - radius, endY = y + radius;
+			if (startY < 0) startY = 0;
+			if (endY >= input.height) endY = input.height - 1;
+			for (int i = startY; i <= endY; i++) {
+				float v = ker[i - y + radius];
+				total += input.get(x, i) * v;
+				div += v;
+			}
+			output.set(x, y / skip, total / div);
+		}
+}
+inline void convolveDownNormalizedHorizontal(const float* ker, int kw, const GrayF32& image, GrayF32& dest, int skip) {
+	downCheck(image, dest, skip);
+	if (kw >= image.width) {
+		downCheckH(image, dest, skip);  // GrayF32.set(x,y,..) bounds check (ImageAccessException)
+		downNaiveHorizontal(ker, kw, image, dest, skip);
+	} else {
+		downCheckH(image, dest, skip);
+		downNoBorderHorizontal(ker, kw, image, dest, skip);
+		downJustBorderHorizontal(ker, kw, image, dest, skip);
+	}
+}
+inline void convolveDownNormalizedVertical(const float* ker, int kw, const GrayF32& image, GrayF32& dest, int skip) {
+	downCheck(image, dest, skip);
+	if (kw >= image.width) {  // sic: the reference tests the WIDTH here too
+		downCheckV(image, dest, skip);  // GrayF32.set(x,y,..) bounds check (ImageAccessException)
+		downNaiveVertical(ker, kw, image, dest, skip);
+	} else {
+		downCheckV(image, dest, skip);
+		downNoBorderVertical(ker, kw, image, dest, skip);
+		downJustBorderVertical(ker, kw, image, dest, skip);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// PyramidDiscreteSampleBlur   I:alg/transform/pyramid/PyramidDiscreteSampleBlur.java:68-126
+//   layer sizes  T:struct/pyramid/ImagePyramidBase.java:73-95  (ceil(bottom/scale); freshly created images are zero,
+//   the convolution writes floor(prev/skip) columns/rows, so a ceil-only last column/row stays 0)
+//   factory  I:factory/transform/pyramid/FactoryPyramid.java:53-61
+// ------------------------------------------------------------------------------------------------
+struct PyramidDiscreteSampleBlur {
+	std::vector<float> kernel;
+	std::vector<int> scale;
+	std::vector<double> sigmas;
+	std::vector<GrayF32> layers;
+	GrayF32 temp;
+	int bottomWidth = 0, bottomHeight = 0;
+
+	PyramidDiscreteSampleBlur(const float* ker, int kw, double sigma, const int* scaleFactors, int n) : kernel(ker, ker + kw), scale(scaleFactors, scaleFactors + n) {
+		// PyramidDiscrete.setScaleFactors -> checkScales (ImagePyramidBase.java:100-112)
+		if (n > 0 && scale[0] < 0) throw DownConvError("The first layer must be more than zero.");
+		int prevScale = 0;
+		for (int s : scale) { if (s < prevScale) throw DownConvError("Higher layers must be the same size or larger than previous layers."); prevScale = s; }
+		sigmas.assign(n, 0.0);
+		for (int i = 1; i < n; i++) {
+			double prev = sigmas[i - 1];
+			double applied = sigma * scale[i - 1];
+			sigmas[i] = std::sqrt(prev * prev + applied * applied);
+		}
+	}
+	void initialize(int width, int height) {
+		if (bottomWidth == width && bottomHeight == height) return;
+		bottomWidth = width; bottomHeight = height;
+		layers.clear();
+		layers.resize(scale.size());
+		for (size_t i = 0; i < scale.size(); i++) {
+			double scaleFactor = scale[i];
+			int w = (int)std::ceil(bottomWidth / scaleFactor), h = (int)std::ceil(bottomHeight / scaleFactor);
+			if (i == 0 && scale[0] == 1) { w = bottomWidth; h = bottomHeight; }
+			layers[i].reshape(w, h);
+			std::fill(layers[i].storage.begin(), layers[i].storage.end(), 0.f);
+		}
+	}
+	void process(const GrayF32& input) {
+		initialize(input.width, input.height);
+		if (scale[0] == 1) {
+			// setFirstLayer(input) / getLayer(0).setTo(input): identical pixel values either way
+			for (int y = 0; y < input.height; y++)
+				for (int x = 0; x < input.width; x++) layers[0].set(x, y, input.get(x, y));
+		} else {
+			int skip = scale[0];
+			temp.reshape(input.width / skip, input.height);
+			convolveDownNormalizedHorizontal(kernel.data(), (int)kernel.size(), input, temp, skip);
+			convolveDownNormalizedVertical(kernel.data(), (int)kernel.size(), temp, layers[0], skip);
+		}
+		for (size_t index = 1; index < scale.size(); index++) {
+			int skip = scale[index] / scale[index - 1];
+			GrayF32& prev = layers[index - 1];
+			temp.reshape(prev.width / skip, prev.height);
+			convolveDownNormalizedHorizontal(kernel.data(), (int)kernel.size(), prev, temp, skip);
+			convolveDownNormalizedVertical(kernel.data(), (int)kernel.size(), temp, layers[index], skip);
+		}
+	}
+};
+
+// ------------------------------------------------------------------------------------------------
 // BRIEF   F:alg/feature/describe/brief/FactoryBriefDefinition.java, DescribePointBinaryCompare.java,
 //         impl/ImplDescribeBinaryCompare_F32.java
 // ------------------------------------------------------------------------------------------------

@@ -293,6 +293,35 @@ void orc_three(const orc_image* in, const orc_image* dx, const orc_image* dy, in
 	GrayF32 x = view(dx), y = view(dy);
 	gradientThree(view(in), x, y, borderZero != 0, threads);
 }
+// down-sampling normalised convolution; returns 0, or -1 where the reference throws / reads out of the image
+int orc_conv_down_norm(int vertical, const float* kernel, int kw, const orc_image* in, const orc_image* out, int skip) {
+	try {
+		GrayF32 o = view(out);
+		if (vertical) convolveDownNormalizedVertical(kernel, kw, view(in), o, skip);
+		else convolveDownNormalizedHorizontal(kernel, kw, view(in), o, skip);
+	} catch (const DownConvError&) { return -1; }
+	return 0;
+}
+int orc_down_max_side(int side, int skip, int radius) { return downComputeMaxSide(side, skip, radius); }
+int orc_down_offset(int skip, int radius) { return downComputeOffset(skip, radius); }
+// PyramidDiscreteSampleBlur.process: layers are written back to back into `out` (capacity outCap floats),
+// dims[2*i], dims[2*i+1] = width, height of layer i, sigmas[i] = getSigma(i).  Returns floats written or -1.
+long orc_pyramid(const float* kernel, int kw, double sigma, const int* scales, int n, const orc_image* in, float* out, long outCap, int* dims, double* sigmas) {
+	try {
+		PyramidDiscreteSampleBlur pyr(kernel, kw, sigma, scales, n);
+		pyr.process(view(in));
+		long off = 0;
+		for (int i = 0; i < n; i++) {
+			const GrayF32& l = pyr.layers[i];
+			dims[2 * i] = l.width; dims[2 * i + 1] = l.height;
+			sigmas[i] = pyr.sigmas[i];
+			if (off + (long)l.width * l.height > outCap) return -1;
+			for (int y = 0; y < l.height; y++)
+				for (int x = 0; x < l.width; x++) out[off++] = l.get(x, y);
+		}
+		return off;
+	} catch (const DownConvError&) { return -1; }
+}
 void orc_subsample(const orc_image* in, const orc_image* out, int skip) { GrayF32 o = view(out); pyramidSubsample(view(in), o, skip); }
 
 }  // extern "C"

@@ -117,6 +117,10 @@ def lib():
             "orc_sobel": (None, [IM, IM, IM, C.c_int, C.c_int]),
             "orc_three": (None, [IM, IM, IM, C.c_int, C.c_int]),
             "orc_subsample": (None, [IM, IM, C.c_int]),
+            "orc_conv_down_norm": (C.c_int, [C.c_int, P(C.c_float), C.c_int, IM, IM, C.c_int]),
+            "orc_down_max_side": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+            "orc_down_offset": (C.c_int, [C.c_int, C.c_int]),
+            "orc_pyramid": (C.c_long, [P(C.c_float), C.c_int, C.c_double, P(C.c_int), C.c_int, IM, P(C.c_float), C.c_long, P(C.c_int), P(C.c_double)]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -341,6 +345,37 @@ def conv(kind, kernel, offset, src, threads=1):
     out = Gray(src.width, src.height)
     getattr(lib(), "orc_conv_" + kind)(kp, len(k), offset, src.c(), out.c(), threads)
     return out
+
+
+def conv_down(kind, kernel, src, skip, out=None):
+    """ConvolveImageDownNormalized.horizontal ('h') / vertical ('v').  `out` defaults to a zeroed image of the
+    smallest legal size; raises ValueError where the reference throws (or would read outside the image)."""
+    k, kp = _kernel(kernel)
+    if out is None:
+        out = Gray(src.width // skip, src.height) if kind == "h" else Gray(src.width, src.height // skip)
+    if lib().orc_conv_down_norm(int(kind == "v"), kp, len(k), src.c(), out.c(), skip) != 0:
+        raise ValueError("down convolution rejected")
+    return out
+
+
+def pyramid(kernel, sigma, scales, src):
+    """PyramidDiscreteSampleBlur(kernel, sigma, scales).process(src) -> (list of layer arrays, sigmas)."""
+    k, kp = _kernel(kernel)
+    sc = np.asarray(scales, dtype=np.int32)
+    cap = int(sum((src.width // max(int(v), 1) + 1) * (src.height // max(int(v), 1) + 1) for v in sc))
+    out = np.zeros(cap, dtype=np.float32)
+    dims = np.zeros(2 * len(sc), dtype=np.int32)
+    sig = np.zeros(len(sc), dtype=np.float64)
+    n = lib().orc_pyramid(kp, len(k), float(sigma), sc.ctypes.data_as(C.POINTER(C.c_int)), len(sc), src.c(), _fp(out), cap,
+                          dims.ctypes.data_as(C.POINTER(C.c_int)), _fp(sig, C.c_double))
+    if n < 0:
+        raise ValueError("pyramid rejected")
+    layers, off = [], 0
+    for i in range(len(sc)):
+        w, h = int(dims[2 * i]), int(dims[2 * i + 1])
+        layers.append(out[off:off + w * h].reshape(h, w).copy())
+        off += w * h
+    return layers, sig
 
 
 def gaussian_blur(src, sigma, radius, threads=1):

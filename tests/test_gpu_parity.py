@@ -395,6 +395,119 @@ def test_gradients_bit_exact(api, orc):
                 assert np.array_equal(bits(dx.array()), bits(ex.array())) and np.array_equal(bits(dy.array()), bits(ey.array())), (w, h, kind, border)
 
 
+def test_down_convolution_bit_exact(api, orc):
+    """ConvolveImageDownNormalized.horizontal/vertical: every (size, radius, skip) class incl. the naive form, the off-grid skip>=3
+    quirk (untouched column keeps the caller's value) and the shapes the reference rejects."""
+    rand = orc.JavaRandom(99)
+    cases = 0
+    for (w, h) in [(15, 20), (16, 21), (80, 120), (41, 27), (201, 133), (9, 64)]:
+        img = rand.fillUniform(orc.Gray(w, h), 1, 10)
+        for r in (1, 2, 3, 4, 5, 7, 10):
+            k = orc.gaussian1d_f32(-1, r)
+            for skip in (1, 2, 3, 4, 5):
+                for kind in ("h", "v"):
+                    ow, oh = (w // skip, h) if kind == "h" else (w, h // skip)
+                    if ow == 0 or oh == 0:
+                        continue
+                    exp = orc.Gray(ow, oh); exp.buf[:] = -3.0
+                    try:
+                        orc.conv_down(kind, k, img, skip, out=exp)
+                    except ValueError:
+                        exp = None
+                    out = api.GrayF32(ow, oh); out.data[:] = -3.0
+                    fn = api.ConvolveImageDownNormalized.horizontal if kind == "h" else api.ConvolveImageDownNormalized.vertical
+                    if exp is None:
+                        with pytest.raises(api.IllegalArgumentException):
+                            fn(api.Kernel1D_F32(k), G(api, img), out, skip)
+                    else:
+                        fn(api.Kernel1D_F32(k), G(api, img), out, skip)
+                        assert np.array_equal(bits(out.array()), bits(exp.array())), (w, h, r, skip, kind)
+                        cases += 1
+    assert cases > 300
+    # kernel that does not sum to one (interior plain sum vs normalised border), even width, sub-images, larger output
+    img = rand.fillUniform(orc.Gray(64, 48), -5, 5)
+    k = np.array([1, 2, 3, 2, 1], np.float32)
+    sub = img.sub_image_of(4, 3)
+    for kind in ("h", "v"):
+        ow, oh = (40, 50) if kind == "h" else (70, 30)
+        exp = orc.Gray(ow, oh).sub_image_of(2, 2, fill=9.0); exp.array()[:, :] = 4.0
+        orc.conv_down(kind, k, sub, 2, out=exp)
+        big = api.GrayF32(ow + 4, oh + 4); big.data[:] = 9.0
+        out = big.subimage(2, 2, 2 + ow, 2 + oh); out.array()[:, :] = 4.0
+        fn = api.ConvolveImageDownNormalized.horizontal if kind == "h" else api.ConvolveImageDownNormalized.vertical
+        fn(api.Kernel1D_F32(k), G(api, sub), out, 2)
+        assert np.array_equal(bits(big.data), bits(exp.buf)), kind
+    for bad_skip, shape in [(0, (32, 48)), (2, (31, 48)), (2, (32, 47))]:
+        with pytest.raises(api.IllegalArgumentException):
+            api.ConvolveImageDownNormalized.horizontal(api.Kernel1D_F32(k), G(api, img), api.GrayF32(*shape), bad_skip)
+    with pytest.raises(api.IllegalArgumentException):  # even kernel on the non-naive path
+        api.ConvolveImageDownNormalized.horizontal(api.Kernel1D_F32(np.ones(4, np.float32)), G(api, img), api.GrayF32(32, 48), 2)
+
+
+@pytest.mark.parametrize("w,h,scales,sigma,radius", [
+    (80, 120, [1, 2, 4], -1, 3),        # TestPyramidDiscreteSampleBlur._update
+    (41, 27, [1, 2, 4], -1, 3),         # odd sizes: ceil layer dims, last row/column stays 0
+    (41, 27, [2, 4, 8], -1, 3),         # scale[0] != 1: layer 0 is convolved too
+    (640, 480, [1, 2, 4, 8], -1, 2),    # FactoryPyramid.discreteGaussian(-1, 2) as the trackers configure it
+    (333, 251, [1, 3, 6], 1.5, -1),
+    (64, 64, [1, 1, 2], -1, 1),         # repeated scale: skip == 1 layer
+    (1920, 1080, [1, 2, 4, 8, 16], -1, 2),
+])
+def test_pyramid_bit_exact(api, orc, w, h, scales, sigma, radius):
+    img = orc.noise_image(w, h, 31, 0, 255)
+    ker = orc.gaussian1d_f32(sigma, radius)
+    exp_layers, exp_sig = orc.pyramid(ker, sigma, scales, img)
+    pyr = api.FactoryPyramid.discreteGaussian(scales, sigma, radius)
+    assert np.array_equal(bits(pyr.kernel.data), bits(ker))
+    pyr.process(G(api, img))
+    assert pyr.getNumLayers() == len(scales)
+    for i, e in enumerate(exp_layers):
+        got = pyr.getLayer(i)
+        assert (got.height, got.width) == e.shape and (pyr.getWidth(i), pyr.getHeight(i)) == (e.shape[1], e.shape[0])
+        assert np.array_equal(bits(got.array()), bits(e)), i
+        assert pyr.getSigma(i) == exp_sig[i] and pyr.getSampleOffset(i) == 0 and pyr.getScale(i) == scales[i]
+    # saveOriginalReference: layer 0 IS the input object
+    if scales[0] == 1:
+        inp = G(api, img)
+        p2 = api.PyramidDiscreteSampleBlur(api.Kernel1D_F32(ker), sigma, True, scales).process(inp)
+        assert p2.getLayer(0) is inp
+        assert np.array_equal(bits(p2.getLayer(len(scales) - 1).array()), bits(exp_layers[-1]))
+
+
+def test_pyramid_rejects_bad_scales(api, orc):
+    ker = api.FactoryKernelGaussian.gaussian1D_F32(-1, 2)
+    with pytest.raises(api.IllegalArgumentException):
+        api.PyramidDiscreteSampleBlur(ker, 1.0, False, [2, 1])
+    with pytest.raises(api.IllegalArgumentException):
+        api.FactoryKernelGaussian.gaussian1D_F32(-1, -1)
+
+
+def test_pyramid_batched_device_equals_single(api, orc):
+    """bhip_pyramid_dev_f32 over a batch of device frames == bhip_pyramid_f32 frame by frame (same stream, no host hop)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from boofcv_amd import _lib
+    L = _lib.load()
+    ctx = api.Context.default()
+    w, h, B, scales = 321, 200, 3, np.array([1, 2, 4, 8], np.int32)
+    frames = np.stack([orc.noise_image(w, h, 50 + b, 0, 255).array() for b in range(B)])
+    ker = api.FactoryKernelGaussian.gaussian1D_F32(-1, 2)
+    dims = np.zeros(8, np.int32); offs = np.zeros(4, np.int64); total = C.c_longlong()
+    assert L.bhip_pyramid_layout(w, h, scales.ctypes.data_as(_lib._ip), 4, dims.ctypes.data_as(_lib._ip), offs.ctypes.data_as(_lib._llp), C.byref(total)) == 0
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.full((B, total.value), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.bhip_pyramid_dev_f32(ctx._h, ker.data.ctypes.data_as(_lib._fp), ker.width, scales.ctypes.data_as(_lib._ip), 4, d_in.data_ptr(), w * h, w, w, h, B,
+                                d_out.data_ptr())
+    assert rc == 0, ctx.lastError()
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    for b in range(B):
+        exp_layers, _ = orc.pyramid(ker.data, -1, scales, orc.Gray.from_array(frames[b]))
+        for i, e in enumerate(exp_layers):
+            assert np.array_equal(bits(got[b, offs[i]:offs[i] + e.size].reshape(e.shape)), bits(e)), (b, i)
+
+
 def test_brief_bit_exact(api, orc):
     sp, cp = orc.brief_definition()  # FactoryBriefDefinition.gaussian2(new Random(123), 16, 512), generated on the host side
     img = orc.noise_image(160, 120, 77)

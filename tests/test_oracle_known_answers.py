@@ -445,3 +445,105 @@ def test_gaussian_tables(orc):
     assert g9.shape == (9, 9) and abs(g9.sum() - 1) < 1e-12 and g9[4, 4] == g9.max()
     g20 = orc.gaussian_width(4.5, 20)
     assert g20.shape == (20, 20) and abs(g20.sum() - 1) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------
+# Down-sampling convolution + discrete pyramid
+# ---------------------------------------------------------------------------------------------------
+def test_down_convolve_util_known_answers(orc):  # IT:alg/filter/convolve/down/TestUtilDownConvolve.java:31-55
+    L = orc.lib()
+    for expect, args in [(8, (10, 1, 1)), (7, (10, 1, 2)), (8, (10, 2, 1)), (6, (10, 2, 2)), (6, (10, 2, 3)), (4, (10, 2, 4)),
+                         (6, (10, 3, 1)), (6, (10, 3, 2)), (6, (10, 3, 3)), (3, (10, 3, 4)), (4, (11, 4, 2))]:
+        assert L.orc_down_max_side(*args) == expect
+    for expect, args in [(1, (1, 1)), (2, (1, 2)), (3, (1, 3)), (2, (2, 1)), (2, (2, 2)), (4, (2, 3))]:
+        assert L.orc_down_offset(*args) == expect
+
+
+def _down_naive64(a, ker, skip, vertical):
+    """Independent restatement: normalised clipped window at every skip-th pixel, in float64."""
+    if vertical:
+        return _down_naive64(a.T, ker, skip, False).T
+    h, w = a.shape
+    r = len(ker) // 2
+    out = np.zeros((h, w // skip))
+    for X in range(w // skip):
+        x = X * skip
+        lo, hi = max(0, x - r), min(w - 1, x + r)
+        kk = np.asarray(ker[lo - x + r:hi - x + r + 1], dtype=np.float64)
+        out[:, X] = (a[:, lo:hi + 1].astype(np.float64) @ kk) / kk.sum()
+    return out
+
+
+def test_down_convolve_normalized_vs_naive(orc):  # IT:alg/filter/convolve/TestConvolveImageDownNormalized.java:30-50
+    rand = orc.JavaRandom(0xFF)
+    for i in range(2):
+        w, h = 15 + i, 20 + i
+        for radius in (1, 2, 3, 10):  # 10: kernel wider than the image -> naive path
+            ker = orc.gaussian1d_f32(-1, radius)
+            src = rand.fillUniform(orc.Gray(w, h), 1, 10)
+            for kind in ("h", "v"):
+                for sub in (False, True):
+                    s = src.sub_image_of() if sub else src
+                    got = orc.conv_down(kind, ker, s, 2).array()
+                    want = _down_naive64(src.array(), ker, 2, kind == "v")
+                    # the Gaussian kernel sums to 1 within float rounding, so interior (plain sum) and naive
+                    # (sum / kernel sum) agree to the reference test's tolerance
+                    assert np.abs(got - want).max() < 1e-4 * 10
+
+
+def test_down_convolve_interior_is_plain_sum_border_is_normalised(orc):
+    """The un-normalised interior is visible with a kernel that does not sum to one."""
+    rand = orc.JavaRandom(3)
+    src = rand.fillUniform(orc.Gray(30, 17), 0, 50)
+    ker = np.array([1, 2, 3, 2, 1], dtype=np.float32)
+    got = orc.conv_down("h", ker, src, 2).array()
+    a = src.array().astype(np.float64)
+    full = np.array([1, 2, 3, 2, 1.0])
+    # left edge x = 0: window clipped to taps 0..+2, divided by their weight
+    assert np.allclose(got[:, 0], (a[:, 0] * 3 + a[:, 1] * 2 + a[:, 2]) / 6, rtol=1e-6)
+    # interior x = 10 and the last interior x = computeMaxSide(30,2,2) = 26: plain sum, NOT divided by 9
+    assert np.allclose(got[:, 5], a[:, 8:13] @ full, rtol=1e-6)
+    assert np.allclose(got[:, 13], a[:, 24:29] @ full, rtol=1e-6)
+    # right edge x = 28: taps -2..+1 only
+    assert np.allclose(got[:, 14], (a[:, 26:30] @ full[:4]) / 8, rtol=1e-6)
+
+
+def test_down_convolve_rejects_bad_shapes(orc):
+    src = orc.Gray(20, 20)
+    ker = orc.gaussian1d_f32(-1, 2)
+    with pytest.raises(ValueError):
+        orc.conv_down("h", ker, src, 0, out=orc.Gray(20, 20))
+    with pytest.raises(ValueError):
+        orc.conv_down("h", ker, src, 2, out=orc.Gray(9, 20))
+    with pytest.raises(ValueError):
+        orc.conv_down("v", ker, src, 2, out=orc.Gray(20, 9))
+
+
+def test_pyramid_discrete_sample_blur_update(orc):  # IT:alg/transform/pyramid/TestPyramidDiscreteSampleBlur.java:44-92
+    width, height = 80, 120
+    rand = orc.JavaRandom(234)
+    inp = rand.fillUniform(orc.Gray(width, height), 0, 100)
+    ker = orc.gaussian1d_f32(-1, 3)
+    layers, _ = orc.pyramid(ker, 3, [1, 2, 4], inp)
+    assert [l.shape for l in layers] == [(120, 80), (60, 40), (30, 20)]
+    assert np.array_equal(layers[0], inp.array())
+    conv = orc.conv("norm_v", ker, 3, orc.conv("norm_h", ker, 3, inp)).array()
+    assert np.abs(conv[::2, ::2] - layers[1]).max() < 1e-4
+    l1 = orc.Gray.from_array(layers[1])
+    conv2 = orc.conv("norm_v", ker, 3, orc.conv("norm_h", ker, 3, l1)).array()
+    assert np.abs(conv2[::2, ::2] - layers[2]).max() < 1e-4
+    # checkModifiesLayersOnUpdate (GenericPyramidTests.java:52-64)
+    assert all(l.sum() > 0 for l in layers)
+
+
+def test_pyramid_sigmas_and_odd_sizes(orc):  # TestPyramidDiscreteSampleBlur.java:97-111
+    ker = orc.gaussian1d_f32(-1, 3)
+    inp = orc.JavaRandom(1).fillUniform(orc.Gray(41, 27), 0, 100)
+    layers, sig = orc.pyramid(ker, 3, [1, 2, 4], inp)
+    assert sig[0] == 0 and abs(sig[1] - 3) < 1e-8 and abs(sig[2] - 6.7082) < 1e-3
+    # ImagePyramidBase.initialize: ceil sizes; the convolution fills floor(prev/skip), the rest stays 0
+    assert [l.shape for l in layers] == [(27, 41), (14, 21), (7, 11)]
+    assert np.all(layers[1][13, :] == 0) and np.all(layers[1][:, 20] == 0) and layers[1][:13, :20].min() > 0
+    layers, sig = orc.pyramid(ker, 3, [2, 4, 8], inp)
+    assert sig[0] == 0 and abs(sig[1] - 6) < 1e-8
+    assert [l.shape for l in layers] == [(14, 21), (7, 11), (4, 6)]
