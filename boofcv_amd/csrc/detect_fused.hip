@@ -387,11 +387,11 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const int X0 = (x0 - R) * SKIP - G::rFmax - 1, Y0 = (y0 - R) * SKIP - G::rFmax - 1;
-	{
+	if (!(P.ablate & 4)) {
 		// stage the patch: every thread keeps a batch of independent global loads in flight before the first LDS store
 		const int tx = tid & 63, ty = tid >> 6;
 		constexpr int COLS = (G::IW + 63) / 64;   // 64-float column chunks per row
-		constexpr int RB = COLS >= 2 ? 4 : 6;     // rows per batch
+		constexpr int RB = (G::IH + 7) / 8;       // rows per batch: the whole patch in two batches of independent loads
 		for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
 			float v[RB][COLS];
 #pragma unroll
@@ -421,15 +421,16 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		}
 	}
 	__syncthreads();
-	fusedLevelFixed<G, SKIP, NL, R, 0>(P, iiT, inten, tid, x0, y0, X0, Y0);
+	if (!(P.ablate & 1)) fusedLevelFixed<G, SKIP, NL, R, 0>(P, iiT, inten, tid, x0, y0, X0, Y0);
 	__syncthreads();
 
-	const int wave = tid >> 6, lane = tid & 63;
-	const int rows = P.nmid * G::TY;
-	for (int row = wave; row < rows; row += 4) {
+	// candidates: ITW-wide rows of lanes (ITW <= 64 is a power of two), so a wave covers 64 / ITW tile rows per pass
+	const int rows = (P.ablate & 2) ? 0 : P.nmid * G::TY;
+	for (int it = tid; it < rows * G::ITW; it += 256) {
+		const int row = it / G::ITW;
+		const int px = it & (G::ITW - 1);
 		const int m = row / G::TY;
 		const int py = row - m * G::TY;
-		const int px = lane;
 		if (px >= G::TX) continue;
 		const FusedMid M = P.mid[m];
 		const int x = x0 + px, y = y0 + py;
@@ -438,6 +439,11 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		const float* mid = inten + M.level * (G::ITH * G::ITp) + (py + R) * G::ITp + (px + R);
 		const float val = mid[0];
 		if (!(val >= P.threshold) || val == FLT_MAX) continue;
+		// most pixels above the threshold lose against a direct neighbour: four reads settle them before the full window is fetched
+		{
+			const float n0 = mid[-1], n1 = mid[1], n2 = mid[-G::ITp], n3 = mid[G::ITp];
+			if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) continue;
+		}
 		// the whole (2R+1)^2 neighbourhood in one batch of LDS reads
 		float nb[(2 * R + 1) * (2 * R + 1)];
 #pragma unroll
@@ -562,12 +568,12 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 		launched = true;                                                                                                               \
 	} while (0)
 			if (arith && skip == 1 && sizes[0] == 9 && step == 6) {
-				if (v == 'a') LAUNCH_FIXED(1, 9, 6, 32, 32);
-				else if (v == 'x') LAUNCH_FIXED(1, 9, 6, 64, 16);
-				else LAUNCH_FIXED(1, 9, 6, 32, 16);
+				if (v == 'a') LAUNCH_FIXED(1, 9, 6, 32, 44);
+				else if (v == 'x') LAUNCH_FIXED(1, 9, 6, 32, 16);
+				else LAUNCH_FIXED(1, 9, 6, 32, 28);   // 28x28 outputs: the (28+4) x 32 intensity tile is exactly 4 passes of 256 threads
 			} else if (arith && skip == 2 && sizes[0] == 15 && step == 12) {
-				if (v == 'a') LAUNCH_FIXED(2, 15, 12, 32, 8);
-				else if (v == 'x') LAUNCH_FIXED(2, 15, 12, 16, 16);
+				if (v == 'a') LAUNCH_FIXED(2, 15, 12, 32, 12);
+				else if (v == 'x') LAUNCH_FIXED(2, 15, 12, 32, 20);
 				else LAUNCH_FIXED(2, 15, 12, 32, 16);
 			}
 #undef LAUNCH_FIXED
