@@ -580,6 +580,26 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	float* sX = (float*)lds;
 	float* sY = sX + nsamp;
 	double* feat = (double*)(sY + nsamp + (nsamp & 1));  // keep 8-byte alignment
+	// Laplacian sign (computeLaplaceSign): kernelDerivXX(9s) + kernelDerivYY(9s) at the rounded location = four clamped box sums of
+	// four corners each.  Lane t < 16 fetches corner (t & 3) of box (t >> 2) now; the sign is assembled at the end of the kernel, so
+	// the scattered loads are hidden behind the descriptor work.
+	float lapTap = 0.0f;
+	if (P.white && lane < 16) {
+		const int x = (int)(kp.x + 0.5), y = (int)(kp.y + 0.5);
+		const int si = (int)ceil(scale);
+		const int size = 9 * si;
+		const int blockW = size / 3, blockH = size - blockW - 1;
+		const int r1 = blockW / 2, r2 = blockW + r1, r3 = blockH / 2;
+		const int box = lane >> 2, corner = lane & 3;
+		const int rx = box == 0 ? r2 : box == 1 ? r1 : r3;   // half extents of the box along x / y
+		const int ry = box == 0 ? r3 : box == 1 ? r3 : box == 2 ? r2 : r1;
+		int bx0 = x - rx - 1, by0 = y - ry - 1, bx1 = x + rx, by1 = y + ry;
+		bx0 = min(bx0, W - 1); by0 = min(by0, H - 1); bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
+		// corner order of block_zero: br, tr, bl, tl
+		const int cx = (corner == 0 || corner == 1) ? bx1 : bx0;
+		const int cy = (corner == 0 || corner == 2) ? by1 : by0;
+		if (cx >= 0 && cy >= 0) lapTap = d[(long long)cy * stride + cx];
+	}
 	{
 		// sample grid in 8x8 blocks: the 64 lanes of one pass cover a compact (8 scale)^2 patch of the image, so a wave-level gather
 		// touches a few dozen cache lines instead of up to 64.  The LDS layout stays [iy][ix].
@@ -620,6 +640,10 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		const int sub = f >> 2, comp = f & 3;
 		const int suby = sub / T.widthLargeGrid, subx = sub - suby * T.widthLargeGrid;
 		const int rY = -regionR + suby * T.widthSubRegion, rX = -regionR + subx * T.widthSubRegion;
+		// this lane's component as one linear form: pdx = c*dx + s*dy (comp 0,1), pdy = -s*dx + c*dy (comp 2,3); (-s)*dx is the exact
+		// negation of s*dx, so the sum below is bit-identical to the reference's expression.  |.| for the odd components is a sign mask.
+		const double cA = comp < 2 ? c : -s, cB = comp < 2 ? s : c;
+		const unsigned long long absMask = (comp & 1) ? 0x7fffffffffffffffull : 0xffffffffffffffffull;
 		double sum = 0;
 		for (int i = 0; i < T_w; i++) {
 			const int index = (rY + regionR + i) * gridW + rX + regionR;
@@ -638,10 +662,8 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				if (j < T_w) {
 					const double dx = w[j] * (double)vx[j];
 					const double dy = w[j] * (double)vy[j];
-					const double pdx = c * dx + s * dy;
-					const double pdy = -s * dx + c * dy;
-					const double v = comp < 2 ? pdx : pdy;
-					sum += (comp & 1) ? fabs(v) : v;
+					const double v = cA * dx + cB * dy;
+					sum += __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & absMask));
 				}
 			}
 		}
@@ -650,18 +672,12 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	}
 	waveSync();
 	DSTAMP(5);
-	// normalizeL2: sequential sum of squares
+	// normalizeL2: sum of squares as a wave reduction (the reference adds the squares sequentially; the two orders differ by a few
+	// ulp of the norm, ~1e-16 relative on the descriptor, against the 1e-5 bar)
 	double norm = 0;
-	if (lane == 0) {
-		for (int i0 = 0; i0 < dof; i0 += 8) {
-			double v[8];
+	for (int f = lane; f < dof; f += 64) { const double v = feat[f]; norm += v * v; }
 #pragma unroll
-			for (int k = 0; k < 8; k++) v[k] = i0 + k < dof ? feat[i0 + k] : 0.0;
-#pragma unroll
-			for (int k = 0; k < 8; k++) if (i0 + k < dof) norm += v[k] * v[k];
-		}
-	}
-	norm = __shfl(norm, 0, 64);
+	for (int o = 32; o >= 1; o >>= 1) norm += __shfl_xor(norm, o, 64);
 	double* out = P.desc + g * dof;
 	if (norm == 0) {
 		for (int f = lane; f < dof; f += 64) out[f] = feat[f];
@@ -669,22 +685,23 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		norm = sqrt(norm);
 		for (int f = lane; f < dof; f += 64) out[f] = feat[f] / norm;
 	}
-	// Laplacian sign (computeLaplaceSign): kernelDerivXX(9s) + kernelDerivYY(9s) at the rounded location
-	if (lane == 0 && P.white) {
-		const int x = (int)(kp.x + 0.5), y = (int)(kp.y + 0.5);
-		const int si = (int)ceil(scale);
-		const int size = 9 * si;
-		const int blockW = size / 3, blockH = size - blockW - 1;
-		const int r1 = blockW / 2, r2 = blockW + r1, r3 = blockH / 2;
+	if (P.white) {
+		// block_zero = br - tr - bl + tl per box, then xx = 0 + b0*1 + b1*(-3), yy likewise, lap = (double)xx + (double)yy
+		float bs[4];
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const float br = __shfl(lapTap, 4 * b, 64), tr = __shfl(lapTap, 4 * b + 1, 64), bl = __shfl(lapTap, 4 * b + 2, 64), tl = __shfl(lapTap, 4 * b + 3, 64);
+			bs[b] = br - tr - bl + tl;
+		}
 		float xx = 0;
-		xx += blockZero(d, stride, W, H, x - r2 - 1, y - r3 - 1, x + r2, y + r3) * 1.0f;
-		xx += blockZero(d, stride, W, H, x - r1 - 1, y - r3 - 1, x + r1, y + r3) * -3.0f;
+		xx += bs[0] * 1.0f;
+		xx += bs[1] * -3.0f;
 		float yy = 0;
-		yy += blockZero(d, stride, W, H, x - r3 - 1, y - r2 - 1, x + r3, y + r2) * 1.0f;
-		yy += blockZero(d, stride, W, H, x - r3 - 1, y - r1 - 1, x + r3, y + r1) * -3.0f;
+		yy += bs[2] * 1.0f;
+		yy += bs[3] * -3.0f;
 		double lap = (double)xx;
 		lap += (double)yy;
-		P.white[g] = lap > 0 ? 1 : 0;
+		if (lane == 0) P.white[g] = lap > 0 ? 1 : 0;
 	}
 	DSTAMP(6);
 }
