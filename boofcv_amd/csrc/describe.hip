@@ -40,6 +40,7 @@ struct DescParams {
 	uint8_t* white;           // [total]
 	int ldsPerWave;           // bytes
 	unsigned long long* stamps; // diagnostic build only: [total][8] cycle stamps
+	int sort64;               // BHIP_DESCRIBE_SORT64=1: always sort on the fp64 keys (cross-check of the 32-bit key sort)
 	int serialOnly;           // BHIP_DESCRIBE_SERIAL=1: always run the reference's serial window sweep (cross-check of the parallel form)
 };
 
@@ -116,9 +117,37 @@ __device__ __forceinline__ void waveSync() {
 // then log2 rounds in which every element finds its slot by a binary search in the sibling run.  All of a lane's searches advance
 // in lock step so each round costs ~log2(L) LDS round trips instead of EPL times that.  On return keyA holds the sorted angles
 // and dX, dY are permuted into the same order.
+//
+// LDS layout of the orientation phase (n samples): while sorting  gX[n] gY[n] (fp32 gradients) | ang[n] (fp64) | 8n bytes of key
+// scratch | idxA[n] idxB[n] (u16) = 28n bytes; afterwards the same bytes hold dX[n] dY[n] sA[n] (fp64, sorted) | Esched[n] (int).
+// The sorted fp64 samples are rebuilt as (double)g * weight[index] -- the expression the reference evaluates -- so only the
+// 4-byte gradients have to live through the sort.
+struct OriSortOut {
+	double* dX; double* dY; double* sA;
+};
 template <int EPLT>
-__device__ __forceinline__ void sortSamplesByAngle(double* dX, double* dY, double* keyA, double* keyB, unsigned short* idxA, unsigned short* idxB, int n,
-													int lane) {
+__device__ __forceinline__ void permuteSorted(const float* gX, const float* gY, const unsigned short* srcI, const double (&a)[EPLT], const double* weights,
+											   OriSortOut o, int p0, int cnt) {
+	double x[EPLT], y[EPLT];
+#pragma unroll
+	for (int e = 0; e < EPLT; e++) {
+		x[e] = 0.0; y[e] = 0.0;
+		if (e < cnt) {
+			const int i = srcI[p0 + e];
+			x[e] = (double)gX[i]; y[e] = (double)gY[i];
+			if (weights) { const double w = weights[i]; x[e] *= w; y[e] *= w; }
+		}
+	}
+	waveSync();
+#pragma unroll
+	for (int e = 0; e < EPLT; e++)
+		if (e < cnt) { o.dX[p0 + e] = x[e]; o.dY[p0 + e] = y[e]; o.sA[p0 + e] = a[e]; }
+	waveSync();
+}
+
+template <int EPLT>
+__device__ __forceinline__ void sortSamplesByAngle(const float* gX, const float* gY, double* keyA, double* keyB, unsigned short* idxA, unsigned short* idxB,
+													const double* weights, OriSortOut out, int n, int lane) {
 	const int EPL = (n + 63) >> 6;   // <= EPLT
 	const int p0 = lane * EPL;
 	const int cnt = max(0, min(EPL, n - p0));
@@ -197,18 +226,124 @@ __device__ __forceinline__ void sortSamplesByAngle(double* dX, double* dY, doubl
 		unsigned short* ti = srcI; srcI = dstI; dstI = ti;
 	}
 	{
-		double x[EPLT], y[EPLT], a[EPLT];
+		double a[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) a[e] = e < cnt ? srcK[p0 + e] : 0.0;
+		permuteSorted<EPLT>(gX, gY, srcI, a, weights, out, p0, cnt);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast form of the same sort on 32-bit keys.  (float)angle is a monotone function of the angle, so ordering by the float's bit
+// pattern (made unsigned-comparable) with a stable merge can only differ from the fp64 (angle, index) order between elements whose
+// floats coincide; those then sit in index order.  After the sort every adjacent pair is checked in fp64: any pair out of order makes
+// the function return false and the caller runs the fp64 sort above on the untouched inputs (a fraction of a percent of key points).
+// The searches compare integers and move 4-byte keys, roughly half the issue slots of the fp64 version.
+__device__ __forceinline__ unsigned int angleKey32(double a) {
+	const float f = (float)a + 0.0f;   // -0 -> +0: equal as doubles, must stay tied
+	const unsigned int u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+template <int EPLT>
+__device__ __forceinline__ bool sortSamplesFast32(const float* gX, const float* gY, const double* ang, unsigned int* keyA, unsigned int* keyB,
+												   unsigned short* idxA, unsigned short* idxB, const double* weights, OriSortOut out, int n, int lane) {
+	const int EPL = (n + 63) >> 6;   // <= EPLT
+	const int p0 = lane * EPL;
+	const int cnt = max(0, min(EPL, n - p0));
+	{
+		unsigned int k[EPLT];
+		unsigned short id[EPLT];
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
-			if (e < cnt) { const int i = srcI[p0 + e]; x[e] = dX[i]; y[e] = dY[i]; a[e] = srcK[p0 + e]; }
+			k[e] = e < cnt ? angleKey32(ang[p0 + e]) : 0xffffffffu;
+			id[e] = (unsigned short)(p0 + e);
 		}
-		waveSync();
 #pragma unroll
-		for (int e = 0; e < EPLT; e++) {
-			if (e < cnt) { dX[p0 + e] = x[e]; dY[p0 + e] = y[e]; keyA[p0 + e] = a[e]; }
+		for (int e = 1; e < EPLT; e++) {
+#pragma unroll
+			for (int f = e; f >= 1; f--) {
+				if (f < cnt && k[f - 1] > k[f]) {
+					const unsigned int tk = k[f]; k[f] = k[f - 1]; k[f - 1] = tk;
+					const unsigned short ti = id[f]; id[f] = id[f - 1]; id[f - 1] = ti;
+				}
+			}
 		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (e < cnt) { keyA[p0 + e] = k[e]; idxA[p0 + e] = id[e]; }
 	}
 	waveSync();
+	unsigned int* srcK = keyA; unsigned int* dstK = keyB;
+	unsigned short* srcI = idxA; unsigned short* dstI = idxB;
+	for (int L = EPL; L < n; L <<= 1) {
+		unsigned int key[EPLT], keyCmp[EPLT];
+		int lo[EPLT], hi[EPLT], base[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int p = p0 + e;
+			const int q = p / L;
+			const int runStart = q * L;
+			const bool right = q & 1;
+			const int sibStart = right ? runStart - L : runStart + L;
+			lo[e] = min(sibStart, n);
+			hi[e] = min(sibStart + L, n);
+			key[e] = e < cnt ? srcK[p] : 0u;
+			// elements of the left run go before equal elements of the right run (stable): a left element counts the siblings
+			// strictly below it, a right element those below or equal, i.e. strictly below key + 1 (keys never reach 0xffffffff)
+			keyCmp[e] = key[e] + (right ? 1u : 0u);
+			base[e] = (right ? sibStart : runStart) + (p - runStart) - min(sibStart, n);
+			if (e >= cnt) hi[e] = lo[e];
+		}
+		for (int span = L; span > 0; span >>= 1) {
+			unsigned int v[EPLT];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				const int mid = (lo[e] + hi[e]) >> 1;
+				v[e] = lo[e] < hi[e] ? srcK[mid] : 0u;
+			}
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				if (lo[e] < hi[e]) {
+					const int mid = (lo[e] + hi[e]) >> 1;
+					if (v[e] < keyCmp[e]) lo[e] = mid + 1; else hi[e] = mid;
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			if (e < cnt) {
+				const int dst = base[e] + lo[e];
+				dstK[dst] = key[e];
+				dstI[dst] = srcI[p0 + e];
+			}
+		}
+		waveSync();
+		unsigned int* tk = srcK; srcK = dstK; dstK = tk;
+		unsigned short* ti = srcI; srcI = dstI; dstI = ti;
+	}
+	// fp64 check of every adjacent pair, then the permutation of the samples into sorted order
+	double a[EPLT];
+	bool bad = false;
+	{
+		int id[EPLT], idn[EPLT];
+		double an[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			id[e] = e < cnt ? srcI[p0 + e] : 0;
+			idn[e] = (e < cnt && p0 + e + 1 < n) ? srcI[p0 + e + 1] : -1;
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			a[e] = ang[id[e]];
+			an[e] = idn[e] >= 0 ? ang[idn[e]] : 0.0;
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (idn[e] >= 0 && (a[e] > an[e] || (a[e] == an[e] && id[e] > idn[e]))) bad = true;
+	}
+	if (__any(bad)) return false;
+	permuteSorted<EPLT>(gX, gY, srcI, a, weights, out, p0, cnt);
+	return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -464,10 +599,13 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		tl_x += 0.5;
 		tl_y += 0.5;
 		const int sw = T.oriWidth, n = sw * sw;
+		// sort-phase layout (see sortSamplesByAngle); the average variant only stages its addends as dX, dY
+		float* gX = (float*)lds;
+		float* gY = gX + n;
+		double* ang = (double*)(lds + (size_t)8 * n);
+		double* keyB = (double*)(lds + (size_t)16 * n);
 		double* dX = (double*)lds;
 		double* dY = dX + n;
-		double* ang = dY + n;
-		double* keyB = ang + n;
 		{
 			// all of this lane's samples: taps first (independent loads in flight together), then the fp64 tail
 			float gx[EPLT], gy[EPLT];
@@ -493,8 +631,8 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 							dx *= w;
 							dy *= w;
 						}
-						dX[idx] = dx;
-						dY[idx] = dy;
+						gX[idx] = gx[e];
+						gY[idx] = gy[e];
 						ang[idx] = atan2(dy, dx);
 					} else {
 						// average variant accumulates w*gx (or gx) in row-major order; stage the addends
@@ -513,13 +651,19 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		waveSync();
 		DSTAMP(1);
 		if (T.oriStable) {
-			unsigned short* idxA = (unsigned short*)(keyB + n);
+			unsigned short* idxA = (unsigned short*)(lds + (size_t)24 * n);
 			unsigned short* idxB = idxA + n;
 			double bestX = 0, bestY = 0;
 			bool needSerial = true;
-			sortSamplesByAngle<EPLT>(dX, dY, ang, keyB, idxA, idxB, n, lane);   // n <= 64 * EPLT is enforced on the host
+			// n <= 64 * EPLT is enforced on the host
+			const OriSortOut so{dX, dY, dY + n};
+			const double* wts = T.oriHasWeights ? T.oriWeights : nullptr;
+			bool sorted = false;
+			if (!P.sort64) sorted = sortSamplesFast32<EPLT>(gX, gY, ang, (unsigned int*)keyB, (unsigned int*)keyB + n, idxA, idxB, wts, so, n, lane);
+			if (!sorted) sortSamplesByAngle<EPLT>(gX, gY, ang, keyB, idxA, idxB, wts, so, n, lane);
+			ang = so.sA;   // sorted angles; dX, dY hold the sorted samples
 			DSTAMP(2);
-			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, (int*)keyB, n, T.oriWindow, lane, bestX, bestY);
+			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY);
 			if (needSerial) {
 				// estimateAngle() exactly as written in the reference, on the arrays already in sorted order (order[k] == k).
 				// Reached for the full-circle regime (all gradients within one window of each other: ramps, flat patches).
@@ -708,7 +852,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 
 int bhip_describe_lds_bytes(const SurfTables& t) {
 	const int n = t.oriWidth * t.oriWidth;
-	const int ori = n * (4 * 8 + 2 * 2) + 16;  // dX, dY, two key buffers (double) + two index buffers (u16)
+	const int ori = n * 28 + 16;  // see sortSamplesByAngle: fp32 gradients + fp64 angles + key scratch + two u16 index buffers
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
@@ -726,6 +870,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	P.ldsPerWave = bhip_describe_lds_bytes(t);
 	P.stamps = nullptr;
 	{ const char* e = getenv("BHIP_DESCRIBE_SERIAL"); P.serialOnly = (e && e[0] == '1') ? 1 : 0; }
+	{ const char* e = getenv("BHIP_DESCRIBE_SORT64"); P.sort64 = (e && e[0] == '1') ? 1 : 0; }
 	if (t.oriWidth * t.oriWidth > 64 * ORI_EPL_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation sample grid too large for the GPU path");
 	if (t.widthSubRegion + 2 * (t.stable ? t.overLap : 0) > DESC_ROW_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "SURF sub-region too wide for the GPU path");
 	if (P.ldsPerWave * 4 > 160 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation/descriptor sample grid too large for LDS");
@@ -773,7 +918,8 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 		const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
 		const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
 		const dim3 grid((unsigned)blocks), block(256);
-		const size_t ldsBytes = (size_t)P.ldsPerWave * 4;
+		size_t ldsBytes = (size_t)P.ldsPerWave * 4;
+		{ const char* e = getenv("BHIP_DESCRIBE_LDSPAD"); if (e) ldsBytes += (size_t)atoi(e); }   // occupancy experiments only
 		if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9>), grid, block, ldsBytes, ctx->stream, P);        // surfStable defaults
 		else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5>), grid, block, ldsBytes, ctx->stream, P);   // surfFast defaults
 		else hipLaunchKernelGGL((k_describe<false, 8, 16>), grid, block, ldsBytes, ctx->stream, P);

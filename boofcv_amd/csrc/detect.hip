@@ -61,7 +61,14 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 	const float* mid = P.mid + (long long)img * P.imageStride;
 	const int stride = P.stride;
 	const int r = P.radius;
-	const float val = mid[(long long)y * stride + x];
+	const float* c = mid + (long long)y * stride + x;
+	const float val = c[0];
+	if (!(val >= P.threshold) || val == FLT_MAX) return;
+	if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+		// most pixels above the threshold lose against a direct neighbour: four independent reads settle them
+		const float n0 = c[-1], n1 = c[1], n2 = c[-stride], n3 = c[stride];
+		if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) return;
+	}
 	if (!strictLocalMax(mid, stride, w, h, x, y, r, val, P.threshold)) return;
 
 	// findLocalScaleSpaceMax: candidates hugging the ignore border are dropped

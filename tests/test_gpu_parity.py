@@ -630,6 +630,37 @@ def test_orientation_degenerate_regimes(api, orc):
     assert np.array_equal(ang, rang) and np.array_equal(desc, rdesc) and np.all(desc == 0)
 
 
+def test_describe_internal_paths_agree(api, orc):
+    """The 32-bit-key sort (with its fp64 check and fallback) must order exactly like the fp64 (angle, index) sort, and the parallel
+    window enumeration must pick the reference's window: angles and descriptors with BHIP_DESCRIBE_SORT64 / BHIP_DESCRIBE_SERIAL are
+    compared against the default path.  Includes images built to produce many equal / nearly equal gradient directions."""
+    import os
+    rng = np.random.default_rng(5)
+    imgs = [orc.noise_image(320, 240, 11)]
+    yy, xx = np.mgrid[0:240, 0:320]
+    imgs.append(orc.Gray.from_array((np.round(20 * np.sin(xx / 7.0) + 20 * np.cos(yy / 5.0)) * 4 + 100).astype(np.float32)))  # quantised: many exact ties
+    imgs.append(orc.Gray.from_array((rng.integers(0, 4, (240, 320)) * 25).astype(np.float32)))                                  # 4 grey levels
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32)
+    for img in imgs:
+        dd.detect(G(api, img))
+        n = dd.getNumberOfFeatures()
+        pts = np.array([[dd.getLocation(i).x, dd.getLocation(i).y, dd.getRadius(i) / 2.0] for i in range(min(n, 400))])
+        if len(pts) == 0:
+            continue
+        base = dd.describePoints(pts)
+        for var in ("BHIP_DESCRIBE_SORT64", "BHIP_DESCRIBE_SERIAL"):
+            os.environ[var] = "1"
+            try:
+                other = dd.describePoints(pts)
+            finally:
+                del os.environ[var]
+            if var == "BHIP_DESCRIBE_SORT64":
+                assert np.array_equal(base[0], other[0]) and np.array_equal(base[2], other[2]), var   # same order -> same bits
+            else:
+                assert np.max(np.abs(np.angle(np.exp(1j * (base[0] - other[0]))))) < 1e-9 and np.max(np.abs(base[2] - other[2])) <= 1e-9, var
+            assert np.array_equal(base[1], other[1])
+
+
 @pytest.mark.parametrize("kind", ["l2", "hamming"])
 def test_sharded_association_single_process_ranks(api, orc, kind):
     """SURVEY 8e on one GPU: R simulated ranks run phase 1 on their row slices, the column records are concatenated exactly as
