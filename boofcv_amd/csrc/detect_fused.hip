@@ -477,6 +477,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		const float interpS = (float)M.sizeMid + peakS * (float)(M.sizeMid - M.sizeLower);
 		const double scale = 1.2 * (double)interpS / 9.0;
 		constexpr int step = R + 1;
+		if (P.ablate & 7) continue;   // timing experiments run on garbage: never emit
 		const unsigned int bit = M.bitBase + (unsigned)((y - b) / step) * (unsigned)M.nbx + (unsigned)((x - b) / step);
 		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
 		const int slot = atomicAdd(&P.candCount[img], 1);
