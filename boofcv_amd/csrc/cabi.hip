@@ -29,9 +29,10 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 void bhip_assoc_mfma_release(AssocMfmaWork& W);
 
 bool bhip_fused_plan(int skip, int nlevels, const int* sizes, int radius, int* TX, int* TY, int* ldsBytes);
+bool bhip_fused_is_fixed(int skip, int nlevels, const int* sizes, int radius);
 int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, int nmid, const DetectLevelParams* mids,
 							 const int* midLevels, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							 int cap);
+							 int cap, const FusedExport* exp);
 
 // per-context scratch that the stateless entry points reuse
 struct CtxScratch {
@@ -132,6 +133,13 @@ struct FhOctavePlan {
 	int skip, w, h, nlevels;
 	int sizes[BHIP_MAX_LEVELS];
 	std::vector<FhLevelPlan> mids;
+	// execution plan (FhDetector::planExecution)
+	bool fused = false, fixed = false;
+	int shareFrom[BHIP_MAX_LEVELS];   // level of the previous octave with the same kernel size, or -1
+	int exportSlot[BHIP_MAX_LEVELS];  // fused producer: slot of this level in the export buffer, or -1
+	int nexport = 0;
+	size_t intenOff = 0, expOff = 0;  // floats, per-image strides below
+	long long intenImageStride = 0, expImageStride = 0;
 };
 
 struct FhDetector {
@@ -139,7 +147,7 @@ struct FhDetector {
 	int W = 0, H = 0, batch = 0, cap = 0;
 	std::vector<FhOctavePlan> plan;
 	int bitmapWords = 0;
-	DevBuf inten, bitmap, prefix, cand, sorted, count;
+	DevBuf inten, expBuf, bitmap, prefix, cand, sorted, count;
 	std::vector<int> counts;   // per image, host
 	long long total = 0;
 
@@ -190,16 +198,71 @@ struct FhDetector {
 		return BHIP_OK;
 	}
 
+	static bool noShare() {
+		static int v = -1;
+		if (v < 0) { const char* e = getenv("BHIP_DETECT_NOSHARE"); v = (e && e[0] == '1') ? 1 : 0; }  // parity cross-check of the shared-level plan
+		return v == 1;
+	}
+	// Which octaves run fused, and which levels are copied from the octave below instead of being recomputed.  A box-filter response
+	// depends on (pixel, kernel size) only, and the default schedule repeats sizes: 15,27 | 27,51 | 51,99 are levels 1,3 of one octave and
+	// levels 0,1 of the next, on a lattice twice as coarse.  Sharing is enabled where the unrolled inner form and the clamped border
+	// form of the reference provably coincide (size = 3*blockSmall, odd), between a producer that keeps or exports its intensity and a
+	// stand-alone consumer.
+	void planExecution() {
+		for (auto& o : plan) {
+			int ftx, fty, flds;
+			o.fused = !unfusedOnly() && !o.mids.empty() && bhip_fused_plan(o.skip, o.nlevels, o.sizes, cfg.extractRadius, &ftx, &fty, &flds);
+			o.fixed = o.fused && bhip_fused_is_fixed(o.skip, o.nlevels, o.sizes, cfg.extractRadius);
+			o.nexport = 0;
+			for (int i = 0; i < BHIP_MAX_LEVELS; i++) { o.shareFrom[i] = -1; o.exportSlot[i] = -1; }
+		}
+		if (noShare()) return;
+		for (size_t k = 1; k < plan.size(); k++) {
+			FhOctavePlan& c = plan[k];
+			FhOctavePlan& p = plan[k - 1];
+			if (c.fused || c.skip != 2 * p.skip) continue;
+			if (p.fused && !p.fixed) continue;
+			for (int i = 0; i < c.nlevels; i++) {
+				const int size = c.sizes[i];
+				if (size % 3 != 0 || size % 2 != 1) continue;
+				for (int j = 0; j < p.nlevels; j++) {
+					if (p.sizes[j] != size) continue;
+					if (p.fused) {
+						if (p.exportSlot[j] < 0) {
+							if (p.nexport >= 2) break;
+							p.exportSlot[j] = p.nexport++;
+						}
+					}
+					c.shareFrom[i] = j;
+					break;
+				}
+			}
+		}
+	}
+
 	int prepare(bhip_ctx* ctx, int width, int height, int batch_) {
-		if (width != W || height != H) BHIP_TRY(makePlan(ctx, width, height));
+		if (width != W || height != H) { BHIP_TRY(makePlan(ctx, width, height)); planExecution(); }
 		W = width; H = height; batch = batch_;
 		if (cap == 0) cap = 8192;
 		return allocate(ctx);
 	}
 	int allocate(bhip_ctx* ctx) {
-		size_t intenBytes = 0;
-		for (auto& o : plan) intenBytes = std::max(intenBytes, (size_t)o.nlevels * o.w * o.h * sizeof(float));
-		BHIP_TRY(inten.reserve(ctx, intenBytes * batch + 16));
+		size_t intenFloats = 0, expFloats = 0;
+		for (size_t k = 0; k < plan.size(); k++) {
+			FhOctavePlan& o = plan[k];
+			if (!o.fused) {
+				o.intenImageStride = (long long)o.nlevels * o.w * o.h;
+				o.intenOff = intenFloats;
+				intenFloats += (size_t)o.intenImageStride * batch;
+			}
+			if (o.nexport > 0 && k + 1 < plan.size()) {
+				o.expImageStride = (long long)o.nexport * plan[k + 1].w * plan[k + 1].h;
+				o.expOff = expFloats;
+				expFloats += (size_t)o.expImageStride * batch;
+			}
+		}
+		BHIP_TRY(inten.reserve(ctx, intenFloats * 4 + 16));
+		BHIP_TRY(expBuf.reserve(ctx, expFloats * 4 + 16));
 		BHIP_TRY(bitmap.reserve(ctx, (size_t)bitmapWords * 4 * batch));
 		BHIP_TRY(prefix.reserve(ctx, (size_t)bitmapWords * 4 * batch));
 		BHIP_TRY(cand.reserve(ctx, (size_t)cap * sizeof(KeyPoint) * batch));
@@ -213,22 +276,38 @@ struct FhDetector {
 		for (int attempt = 0; attempt < 8; attempt++) {
 			BHIP_HIP(ctx, hipMemsetAsync(bitmap.p, 0, (size_t)bitmapWords * 4 * batch, ctx->stream));
 			BHIP_HIP(ctx, hipMemsetAsync(count.p, 0, (size_t)batch * 4 * 2, ctx->stream));
-			for (auto& o : plan) {
-				int ftx, fty, flds;
-				if (!unfusedOnly() && !o.mids.empty() && bhip_fused_plan(o.skip, o.nlevels, o.sizes, cfg.extractRadius, &ftx, &fty, &flds)) {
-					// LDS-tiled fused octave: intensity never leaves the CU
+			for (size_t k = 0; k < plan.size(); k++) {
+				FhOctavePlan& o = plan[k];
+				if (o.fused) {
+					// LDS-tiled fused octave: intensity never leaves the CU (except the levels the next octave shares)
 					DetectLevelParams mp[BHIP_MAX_LEVELS];
 					int ml[BHIP_MAX_LEVELS];
-					for (size_t k = 0; k < o.mids.size(); k++) { mp[k] = o.mids[k].p; ml[k] = o.mids[k].level; }
+					for (size_t q = 0; q < o.mids.size(); q++) { mp[q] = o.mids[q].p; ml[q] = o.mids[q].level; }
+					FusedExport ex{0, {0, 0}, nullptr, 0, 0, 0};
+					if (o.nexport > 0 && k + 1 < plan.size()) {
+						ex.n = o.nexport;
+						for (int j = 0; j < o.nlevels; j++) if (o.exportSlot[j] >= 0) ex.level[o.exportSlot[j]] = j;
+						ex.out = expBuf.as<float>() + o.expOff; ex.w = plan[k + 1].w; ex.h = plan[k + 1].h; ex.imageStride = o.expImageStride;
+					}
 					BHIP_TRY(bhip_launch_detect_fused(ctx, ii, batch, o.skip, o.nlevels, o.sizes, (int)o.mids.size(), mp, ml, cfg.extractRadius,
-													  cfg.detectThreshold, bitmap.as<unsigned int>(), bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap));
+													  cfg.detectThreshold, bitmap.as<unsigned int>(), bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap,
+													  ex.n > 0 ? &ex : nullptr));
 					continue;
 				}
 				const long long levelStride = (long long)o.w * o.h;
-				const long long imageStride = levelStride * o.nlevels;
-				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, inten.as<float>(), levelStride, imageStride, o.w));
+				const long long imageStride = o.intenImageStride;
+				float* base = inten.as<float>() + o.intenOff;
+				HessLevelSource from[BHIP_MAX_LEVELS];
+				for (int i = 0; i < o.nlevels; i++) {
+					from[i] = HessLevelSource{nullptr, 0, 0, 1};
+					const int j = o.shareFrom[i];
+					if (j < 0 || k == 0) continue;
+					const FhOctavePlan& p = plan[k - 1];
+					if (p.fused) from[i] = HessLevelSource{expBuf.as<float>() + p.expOff + (size_t)p.exportSlot[j] * levelStride, p.expImageStride, o.w, 1};
+					else from[i] = HessLevelSource{inten.as<float>() + p.intenOff + (size_t)j * p.w * p.h, p.intenImageStride, p.w, 2};
+				}
+				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, base, levelStride, imageStride, o.w, from));
 				for (auto& m : o.mids) {
-					const float* base = inten.as<float>();
 					BHIP_TRY(bhip_launch_nms_scalespace(ctx, base + (m.level - 1) * levelStride, base + m.level * levelStride, base + (m.level + 1) * levelStride,
 														imageStride, o.w, batch, m.p, cfg.extractRadius, cfg.detectThreshold, bitmap.as<unsigned int>(),
 														bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap));
@@ -258,7 +337,7 @@ struct FhDetector {
 		}
 		return bhip_fail(ctx, BHIP_ERR_CAPACITY, "key point list kept overflowing");
 	}
-	void release() { inten.release(); bitmap.release(); prefix.release(); cand.release(); sorted.release(); count.release(); }
+	void release() { inten.release(); expBuf.release(); bitmap.release(); prefix.release(); cand.release(); sorted.release(); count.release(); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------

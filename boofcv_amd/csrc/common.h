@@ -132,8 +132,23 @@ std::vector<float> bhip_gaussian1d_f32(double sigma, int radius);           // F
 
 // ---------------- kernel launchers (defined in the .hip files) ----------------
 int bhip_launch_integral(bhip_ctx* ctx, ImgView in, ImgViewW out, int batch);
+// levels a fused octave writes out for the next octave (every second pixel, next octave's [image][slot][h][w] layout)
+struct FusedExport {
+	int n;
+	int level[2];
+	float* out;
+	int w, h;
+	long long imageStride;
+};
+// where a stand-alone Hessian level comes from: computed, or copied from a level of the same kernel size one octave down
+struct HessLevelSource {
+	const float* src;        // nullptr: compute
+	long long imageStride;   // floats between images at src
+	int stride;              // floats between rows at src
+	int step;                // 1: src already has this octave's layout, 2: take every second pixel
+};
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
-						long long imageStrideOut, int outStride);
+						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr);
 
 struct DetectLevelParams {
 	int skip, w, h;              // intensity image size

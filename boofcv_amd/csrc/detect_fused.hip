@@ -46,6 +46,15 @@ struct FusedParams {
 	KeyPoint* cand;
 	int* candCount;
 	int cap;
+	int batch;
+	// Levels whose kernel size appears again in the next octave (size 27 and 51 of octave 1 are levels 0 and 1 of octave 2, ...): the
+	// intensity of a pixel does not depend on the sampling step, so every second pixel of those levels is written out in the next
+	// octave's layout [image][slot][expH][expW] and the next octave copies instead of recomputing (hessian.hip).
+	int nexp;
+	int expLevel[2];
+	float* expOut;
+	int expW, expH;
+	long long expImageStride;
 	int ablate;   // timing experiments only (BHIP_FUSED_ABLATE): 1 skip the intensity phase, 2 skip the NMS phase, 4 skip staging
 };
 
@@ -374,12 +383,18 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	float* iiT = fl;
 	float* inten = fl + SKIP * G::plane;
 	const int tid = threadIdx.x;
-	int bx = blockIdx.x, by = blockIdx.y, img = blockIdx.z;
-	if (P.ablate & 16) {   // experiment: 1-D grid, image-major
+	// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one L2), so block b takes
+	// tile (b % 8) * chunk + b / 8 -- every XCD walks its own contiguous run of tiles (row after row of one image) and the halo
+	// re-reads of neighbouring tiles hit that XCD's 4 MB L2 instead of going out to the fabric.  Speed only, never correctness.
+	int bx, by, img;
+	{
 		const int tilesX = (P.w + G::TX - 1) / G::TX, tilesY = (P.h + G::TY - 1) / G::TY;
-		const int lin = blockIdx.x;
-		img = lin / (tilesX * tilesY);
-		const int rem = lin - img * tilesX * tilesY;
+		const long long ntiles = (long long)tilesX * tilesY * P.batch;
+		const long long chunk = (ntiles + 7) >> 3;
+		const long long lin = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+		if ((blockIdx.x >> 3) >= chunk || lin >= ntiles) return;
+		img = (int)(lin / ((long long)tilesX * tilesY));
+		const int rem = (int)(lin - (long long)img * tilesX * tilesY);
 		by = rem / tilesX;
 		bx = rem - by * tilesX;
 	}
@@ -423,6 +438,21 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	__syncthreads();
 	if (!(P.ablate & 1)) fusedLevelFixed<G, SKIP, NL, R, 0>(P, iiT, inten, tid, x0, y0, X0, Y0);
 	__syncthreads();
+	if (P.nexp > 0) {
+		// even pixels of the tile core -> pixel (x/2, y/2) of the next octave
+		constexpr int HX = (G::TX + 1) / 2, HY = (G::TY + 1) / 2;
+		const int ex0 = (x0 + 1) >> 1, ey0 = (y0 + 1) >> 1;   // first even pixel of the core, in next-octave coordinates
+		for (int it = tid; it < P.nexp * HX * HY; it += 256) {
+			const int k = it / (HX * HY);
+			const int rem = it - k * (HX * HY);
+			const int jy = rem / HX, jx = rem - jy * HX;
+			const int ex = ex0 + jx, ey = ey0 + jy;
+			const int px = 2 * ex - x0, py = 2 * ey - y0;   // core coordinates in this tile
+			if (px < G::TX && py < G::TY && 2 * ex < P.w && 2 * ey < P.h && ex < P.expW && ey < P.expH)
+				P.expOut[(long long)img * P.expImageStride + ((long long)k * P.expH + ey) * P.expW + ex] =
+					inten[P.expLevel[k] * (G::ITH * G::ITp) + (py + R) * G::ITp + (px + R)];
+		}
+	}
 
 	// candidates: ITW-wide rows of lanes (ITW <= 64 is a power of two), so a wave covers 64 / ITW tile rows per pass
 	const int rows = (P.ablate & 2) ? 0 : P.nmid * G::TY;
@@ -517,9 +547,18 @@ bool bhip_fused_plan(int skip, int nlevels, const int* sizes, int radius, int* T
 	return false;
 }
 
+// true when the octave runs on the compile-time-geometry kernel (the only fused kernel that can export levels)
+bool bhip_fused_is_fixed(int skip, int nlevels, const int* sizes, int radius) {
+	if (nlevels != 4 || radius != 2) return false;
+	{ const char* e = getenv("BHIP_FUSED_ABLATE"); if (e && (atoi(e) & 8)) return false; }
+	const int step = sizes[1] - sizes[0];
+	if (sizes[2] - sizes[1] != step || sizes[3] - sizes[2] != step) return false;
+	return (skip == 1 && sizes[0] == 9 && step == 6) || (skip == 2 && sizes[0] == 15 && step == 12);
+}
+
 int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, int nmid, const DetectLevelParams* mids,
 							 const int* midLevels, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							 int cap) {
+							 int cap, const FusedExport* exp) {
 	FusedParams P;
 	int TX, TY, lds;
 	if (!bhip_fused_plan(skip, nlevels, sizes, radius, &TX, &TY, &lds)) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "octave does not fit the fused tile");
@@ -544,12 +583,17 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 	P.IW = (TX - 1 + 2 * radius) * skip + 2 * rFmax + 2;
 	P.IH = (TY - 1 + 2 * radius) * skip + 2 * rFmax + 2;
 	P.IWp = P.IW | 1;
-	P.radius = radius; P.threshold = threshold; P.nmid = nmid;
+	P.radius = radius; P.threshold = threshold; P.nmid = nmid; P.batch = batch;
 	for (int m = 0; m < nmid; m++) {
 		P.mid[m].level = midLevels[m]; P.mid[m].border = mids[m].border; P.mid[m].nbx = mids[m].nbx; P.mid[m].bitBase = mids[m].bitBase;
 		P.mid[m].sizeMid = mids[m].sizeMid; P.mid[m].sizeLower = mids[m].sizeLower;
 	}
 	{ const char* e = getenv("BHIP_FUSED_ABLATE"); P.ablate = e ? atoi(e) : 0; }
+	P.nexp = 0; P.expOut = nullptr; P.expW = P.expH = 0; P.expImageStride = 0; P.expLevel[0] = P.expLevel[1] = 0;
+	if (exp && exp->n > 0) {
+		P.nexp = exp->n; P.expLevel[0] = exp->level[0]; P.expLevel[1] = exp->level[1];
+		P.expOut = exp->out; P.expW = exp->w; P.expH = exp->h; P.expImageStride = exp->imageStride;
+	}
 	P.bitmap = bitmap; P.bitmapWords = bitmapWords; P.cand = cand; P.candCount = candCount; P.cap = cap;
 	dim3 grid((P.w + TX - 1) / TX, (P.h + TY - 1) / TY, batch);
 	{
@@ -564,7 +608,8 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 #define LAUNCH_FIXED(SK, S0, ST, ITWV, TYV)                                                                                             \
 	do {                                                                                                                               \
 		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV> G;                                                                               \
-		dim3 g((P.w + G::TX - 1) / G::TX, (P.h + G::TY - 1) / G::TY, batch);                                                            \
+		const long long nt = (long long)((P.w + G::TX - 1) / G::TX) * ((P.h + G::TY - 1) / G::TY) * batch;                              \
+		dim3 g((unsigned)(((nt + 7) >> 3) << 3));                                                                                      \
 		hipLaunchKernelGGL((k_detect_fused_fixed<SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
 		launched = true;                                                                                                               \
 	} while (0)
@@ -579,7 +624,10 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 			}
 #undef LAUNCH_FIXED
 		}
-		if (!launched) hipLaunchKernelGGL(k_detect_fused, grid, dim3(256), (size_t)lds, ctx->stream, P);
+		if (!launched) {
+			if (P.nexp > 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "level export needs the fixed-geometry fused kernel");
+			hipLaunchKernelGGL(k_detect_fused, grid, dim3(256), (size_t)lds, ctx->stream, P);
+		}
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

@@ -26,6 +26,7 @@ struct HessParams {
 	long long levelStride, imageStrideOut;
 	int outStride;
 	HessLevel lv[BHIP_MAX_LEVELS];
+	HessLevelSource from[BHIP_MAX_LEVELS];
 };
 
 __device__ __forceinline__ float block_zero(const float* __restrict__ d, int stride, int W, int H, int x0, int y0, int x1, int y1) {
@@ -51,6 +52,13 @@ __global__ __launch_bounds__(256) void k_hessian(HessParams P) {
 	const int img = blockIdx.z / P.nlevels;
 	const int level = blockIdx.z - img * P.nlevels;
 	if (x >= P.w) return;
+	if (P.from[level].src) {
+		// same kernel size one octave down: the intensity of a pixel does not depend on the sampling step
+		const HessLevelSource S = P.from[level];
+		P.out[(long long)img * P.imageStrideOut + (long long)level * P.levelStride + (long long)y * P.outStride + x] =
+			S.src[(long long)img * S.imageStride + (long long)(y * S.step) * S.stride + x * S.step];
+		return;
+	}
 	const HessLevel L = P.lv[level];
 	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride;
@@ -128,7 +136,7 @@ static HessLevel makeLevel(int size, int skip) {
 }
 
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
-						long long imageStrideOut, int outStride) {
+						long long imageStrideOut, int outStride, const HessLevelSource* from) {
 	if (nlevels > BHIP_MAX_LEVELS) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "too many scales per octave");
 	HessParams P;
 	P.ii = ii;
@@ -140,7 +148,10 @@ int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlev
 	P.levelStride = levelStride;
 	P.imageStrideOut = imageStrideOut;
 	P.outStride = outStride;
-	for (int i = 0; i < nlevels; i++) P.lv[i] = makeLevel(sizes[i], skip);
+	for (int i = 0; i < nlevels; i++) {
+		P.lv[i] = makeLevel(sizes[i], skip);
+		P.from[i] = from ? from[i] : HessLevelSource{nullptr, 0, 0, 1};
+	}
 	if (P.w <= 0 || P.h <= 0) return BHIP_OK;
 	dim3 grid((P.w + 255) / 256, P.h, batch * nlevels);
 	{

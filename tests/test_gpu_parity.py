@@ -630,6 +630,30 @@ def test_orientation_degenerate_regimes(api, orc):
     assert np.array_equal(ang, rang) and np.array_equal(desc, rdesc) and np.all(desc == 0)
 
 
+def test_detector_plans_agree(api, orc, tmp_path):
+    """The detector has three execution plans that must give the same key points bit for bit: fused octaves + levels shared between
+    octaves (default), no sharing (BHIP_DETECT_NOSHARE=1), and the stand-alone kernels for every octave (BHIP_DETECT_UNFUSED=1, with
+    and without sharing).  The switches are read once per process, so the variants run in child processes."""
+    import os, subprocess, sys
+    img = orc.noise_image(700, 520, 21, 0, 255)
+    np.save(tmp_path / "img.npy", img.array())
+    fh = api.FastHessianFeatureDetector(api.ConfigFastHessian(1, 2, -1, 1, 9, 4, 4))
+    ii = api.IntegralImageOps.transform(G(api, img))
+    fh.detect(ii)
+    base = fh.getFoundPoints().copy()
+    assert len(base) > 500 and np.array_equal(base, orc.fh_detect(orc.integral(img), orc.FhCfg()))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from boofcv_amd import api; "
+            "a = np.load(%r); fh = api.FastHessianFeatureDetector(api.ConfigFastHessian(1, 2, -1, 1, 9, 4, 4)); "
+            "fh.detect(api.IntegralImageOps.transform(api.GrayF32.wrap(a))); "
+            "np.save(%r, fh.getFoundPoints())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k, env in enumerate([{"BHIP_DETECT_NOSHARE": "1"}, {"BHIP_DETECT_UNFUSED": "1"}, {"BHIP_DETECT_UNFUSED": "1", "BHIP_DETECT_NOSHARE": "1"}]):
+        out = str(tmp_path / ("kp%d.npy" % k))
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "img.npy"), out)], check=True, env=e, timeout=300)
+        assert np.array_equal(np.load(out), base), env
+
+
 def test_describe_internal_paths_agree(api, orc):
     """The 32-bit-key sort (with its fp64 check and fallback) must order exactly like the fp64 (angle, index) sort, and the parallel
     window enumeration must pick the reference's window: angles and descriptors with BHIP_DESCRIBE_SORT64 / BHIP_DESCRIBE_SERIAL are
