@@ -561,7 +561,13 @@ template <bool STAMP, int EPLT, int TWT>
 __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ldsAll[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const long long g = (long long)blockIdx.x * 4 + wave;
+	// XCD-aware order (blocks are dealt round-robin over the 8 XCDs): block b takes key-point group (b % 8) * chunk + b / 8, so each
+	// XCD works through its own contiguous run of key points -- one or two images at a time in its L2 instead of the whole batch
+	const long long nblk = (P.total + 3) >> 2;
+	const long long chunk = (nblk + 7) >> 3;
+	const long long blk = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+	if ((long long)(blockIdx.x >> 3) >= chunk) return;
+	const long long g = blk * 4 + wave;
 	if (g >= P.total) return;
 	unsigned char* lds = ldsAll + (size_t)wave * P.ldsPerWave;
 
@@ -874,7 +880,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	if (t.oriWidth * t.oriWidth > 64 * ORI_EPL_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation sample grid too large for the GPU path");
 	if (t.widthSubRegion + 2 * (t.stable ? t.overLap : 0) > DESC_ROW_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "SURF sub-region too wide for the GPU path");
 	if (P.ldsPerWave * 4 > 160 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation/descriptor sample grid too large for LDS");
-	const long long blocks = (total + 3) / 4;
+	const long long blocks = ((((total + 3) / 4) + 7) / 8) * 8;   // whole rounds over the 8 XCDs
 	if (blocks > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_INVALID, "too many key points");
 	const char* stampPath = getenv("BHIP_DESCRIBE_STAMPS");
 	if (stampPath && total > 1000) {
