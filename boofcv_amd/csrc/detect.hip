@@ -15,17 +15,34 @@
 #include "common.h"
 #include <cfloat>
 
-// strict-maximum test of NonMaxBlockSearchStrict.Max for pixel (x,y) with value v
+// strict-maximum test of NonMaxBlockSearchStrict.Max for pixel (x,y) with value v.  The window is read without early exits so the
+// loads are independent (a branch per load turns the window into a chain of dependent memory round trips).
+template <int RT>   // RT > 0: compile-time radius, fully unrolled; RT == 0: run-time radius r
 __device__ __forceinline__ bool strictLocalMax(const float* __restrict__ img, int stride, int w, int h, int x, int y, int r, float v, float thr) {
 	if (!(v >= thr) || v == FLT_MAX) return false;
-	const int x0 = max(x - r, 0), x1 = min(x + r, w - 1), y0 = max(y - r, 0), y1 = min(y + r, h - 1);
-	for (int j = y0; j <= y1; j++) {
-		const float* row = img + (long long)j * stride;
-		for (int i = x0; i <= x1; i++) {
-			if (row[i] >= v && !(i == x && j == y)) return false;
+	bool isMax = true;
+	if (RT > 0) {
+		float nb[(2 * RT + 1) * (2 * RT + 1)];
+#pragma unroll
+		for (int j = -RT; j <= RT; j++)
+#pragma unroll
+			for (int i = -RT; i <= RT; i++) {
+				const int xx = x + i, yy = y + j;
+				const bool in = xx >= 0 && xx < w && yy >= 0 && yy < h && !(i == 0 && j == 0);
+				nb[(j + RT) * (2 * RT + 1) + i + RT] = in ? img[(long long)yy * stride + xx] : -INFINITY;
+			}
+#pragma unroll
+		for (int k = 0; k < (2 * RT + 1) * (2 * RT + 1); k++)
+			if (nb[k] >= v) isMax = false;
+	} else {
+		const int x0 = max(x - r, 0), x1 = min(x + r, w - 1), y0 = max(y - r, 0), y1 = min(y + r, h - 1);
+		for (int j = y0; j <= y1; j++) {
+			const float* row = img + (long long)j * stride;
+			for (int i = x0; i <= x1; i++)
+				if (row[i] >= v && !(i == x && j == y)) isMax = false;
 		}
 	}
-	return true;
+	return isMax;
 }
 
 __device__ __forceinline__ float polyPeak(float lower, float middle, float upper) {
@@ -51,39 +68,58 @@ struct NmsParams {
 	int cap;
 };
 
+#define NMS_ROWS 4   // rows per thread: the column neighbours are shared and the grid has 4x fewer, longer-lived blocks
 __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 	const int b = P.p.border;
 	const int w = P.p.w, h = P.p.h;
 	const int x = b + blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = b + blockIdx.y;
+	const int yBase = b + blockIdx.y * NMS_ROWS;
 	const int img = blockIdx.z;
-	if (x >= w - b || y >= h - b) return;
+	if (x >= w - b) return;
 	const float* mid = P.mid + (long long)img * P.imageStride;
 	const int stride = P.stride;
 	const int r = P.radius;
-	const float* c = mid + (long long)y * stride + x;
-	const float val = c[0];
-	if (!(val >= P.threshold) || val == FLT_MAX) return;
-	if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-		// most pixels above the threshold lose against a direct neighbour: four independent reads settle them
-		const float n0 = c[-1], n1 = c[1], n2 = c[-stride], n3 = c[stride];
-		if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) return;
+	// column values for rows yBase-1 .. yBase+NMS_ROWS and the left / right neighbours of the NMS_ROWS centre rows, all independent loads
+	float col[NMS_ROWS + 2], lf[NMS_ROWS], rt[NMS_ROWS];
+#pragma unroll
+	for (int k = 0; k < NMS_ROWS + 2; k++) {
+		const int yy = yBase - 1 + k;
+		col[k] = (yy >= 0 && yy < h) ? mid[(long long)yy * stride + x] : -INFINITY;
 	}
-	if (!strictLocalMax(mid, stride, w, h, x, y, r, val, P.threshold)) return;
+#pragma unroll
+	for (int k = 0; k < NMS_ROWS; k++) {
+		const int yy = yBase + k;
+		const bool rowIn = yy < h;
+		lf[k] = (rowIn && x >= 1) ? mid[(long long)yy * stride + x - 1] : -INFINITY;
+		rt[k] = (rowIn && x + 1 < w) ? mid[(long long)yy * stride + x + 1] : -INFINITY;
+	}
+#pragma unroll 1
+	for (int k = 0; k < NMS_ROWS; k++) {
+	const int y = yBase + k;
+	if (y >= h - b) break;
+	const float val = col[k + 1];
+	if (!(val >= P.threshold) || val == FLT_MAX) continue;
+	// most pixels above the threshold lose against a direct neighbour (r >= 1, so the four are inside the strict-max window)
+	if (lf[k] >= val || rt[k] >= val || col[k] >= val || col[k + 2] >= val) continue;
+	if (!(r == 2 ? strictLocalMax<2>(mid, stride, w, h, x, y, r, val, P.threshold) : strictLocalMax<0>(mid, stride, w, h, x, y, r, val, P.threshold))) continue;
 
 	// findLocalScaleSpaceMax: candidates hugging the ignore border are dropped
 	const int ignoreR = b + r;
-	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) return;
+	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) continue;
 	const float* lower = P.lower + (long long)img * P.imageStride;
 	const float* upper = P.upper + (long long)img * P.imageStride;
 	// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
+	bool below = true;
+#pragma unroll
 	for (int j = y - 1; j <= y + 1; j++)
+#pragma unroll
 		for (int i = x - 1; i <= x + 1; i++) {
 			const bool in = i >= 0 && i < w && j >= 0 && j < h;
 			const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
 			const float up = in ? upper[(long long)j * stride + i] : 0.0f;
-			if (lo >= val || up >= val) return;
+			if (lo >= val || up >= val) below = false;
 		}
+	if (!below) continue;
 	const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
 	const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
 	const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
@@ -105,6 +141,7 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 		kp.pad = 0;
 		P.cand[(long long)img * P.cap + slot] = kp;
 	}
+	}
 }
 
 int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
@@ -113,7 +150,7 @@ int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* m
 	const int rw = p.w - 2 * p.border, rh = p.h - 2 * p.border;
 	if (rw <= 0 || rh <= 0) return BHIP_OK;
 	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap};
-	dim3 grid((rw + 255) / 256, rh, batch);
+	dim3 grid((rw + 255) / 256, (rh + NMS_ROWS - 1) / NMS_ROWS, batch);
 	{
 		ProfScope ps(ctx, "k_nms_scalespace", 4.0 * p.w * p.h * batch);  // the mid level read once
 		hipLaunchKernelGGL(k_nms_scalespace, grid, dim3(256), 0, ctx->stream, P);
@@ -198,7 +235,7 @@ __global__ __launch_bounds__(256) void k_nonmax_only(const float* __restrict__ i
 	const int y = border + blockIdx.y;
 	if (x >= w - border || y >= h - border) return;
 	const float v = img[(long long)y * stride + x];
-	if (!strictLocalMax(img, stride, w, h, x, y, radius, v, thr)) return;
+	if (!strictLocalMax<0>(img, stride, w, h, x, y, radius, v, thr)) return;
 	const int step = radius + 1;
 	const unsigned int bit = (unsigned)((y - border) / step) * (unsigned)nbx + (unsigned)((x - border) / step);
 	atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
@@ -223,7 +260,7 @@ __global__ __launch_bounds__(256) void k_bitmap_to_xy(const float* __restrict__ 
 	const int y = border + blockIdx.y;
 	if (x >= w - border || y >= h - border) return;
 	const float v = img[(long long)y * stride + x];
-	if (!strictLocalMax(img, stride, w, h, x, y, radius, v, thr)) return;
+	if (!strictLocalMax<0>(img, stride, w, h, x, y, radius, v, thr)) return;
 	const int step = radius + 1;
 	const unsigned int bit = (unsigned)((y - border) / step) * (unsigned)nbx + (unsigned)((x - border) / step);
 	const unsigned int word = bit >> 5;
