@@ -91,6 +91,25 @@ class HotPath:
         return total
 
 
+def pmc_traffic(tag, batch, height, width):
+    """HBM-side bytes per launch of kernel `tag` from the committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json, collected by
+    scripts/pmc_traffic.sh on this workload and corrected as its header says); None when no summary matches the workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        wl = d.get("workload", {})
+        if (wl.get("batch"), wl.get("height"), wl.get("width")) != (batch, height, width):
+            continue
+        name = d.get("bench_tags", {}).get(tag, tag)
+        rec = d.get("kernels", {}).get(name)
+        if rec:
+            return rec["bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(frames_cpu, threads):
     """The oracle restatement of the same step on host cores: detect+describe every frame, associate consecutive frames."""
     from oracle import pyoracle as orc
@@ -186,6 +205,11 @@ def main():
                 roofline = {"kernel": tag, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(achieved / peak, 4), "traffic": None,
                             "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"]}
+            tb, src = pmc_traffic(tag, B, H, W)
+            if tb is not None:
+                roofline["traffic"] = tb
+                roofline["traffic_note"] = "bytes per launch leaving the XCD L2s (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC), from " + src
+                roofline["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["launches"]) if r["bytes"] > 0 else None
             roofline["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             roofline["hbm_gbs_by_kernel"] = {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}
             roofline["tflops_by_kernel"] = {k: round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}

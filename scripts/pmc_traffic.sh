@@ -1,0 +1,28 @@
+# HBM-side traffic of every own kernel (rocprofv3 PMC, FETCH_SIZE and WRITE_SIZE in separate passes as the TCC slots require).
+# Writes gpurun_out/pmc_traffic/summary.json: per kernel, counter sums / launches.  Batch is the bench default (256).
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmc_traffic && mkdir -p gpurun_out/pmc_traffic
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic/$c -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 > gpurun_out/pmc_traffic/$c.log 2>&1 || exit 1
+done
+python3 - <<'PY'
+import csv, glob, collections, json
+out = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob('gpurun_out/pmc_traffic/%s/**/*counter_collection.csv' % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != c:
+                continue
+            k = r['Kernel_Name']
+            if not (k.startswith('k_') or k.startswith('void k_')):
+                continue
+            k = k.split('(')[0].replace('void ', '')
+            agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
+    for k, (v, n) in agg.items():
+        out.setdefault(k, {})[c] = {"sum": v, "launches": n, "per_launch": v / n}
+json.dump(out, open('gpurun_out/pmc_traffic/summary.json', 'w'), indent=1)
+for k, v in sorted(out.items()):
+    print(k, {c: round(x["per_launch"], 1) for c, x in v.items()})
+PY
+find gpurun_out/pmc_traffic -name "*.csv" -size +2M -delete
