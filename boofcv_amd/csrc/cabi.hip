@@ -8,7 +8,8 @@
 
 // launchers defined in the other translation units
 int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int cap, const int* imageStart, int batch, int singleImage, long long total,
-							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white);
+							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white, const int* perm = nullptr);
+int bhip_launch_kp_spatial_order(bhip_ctx* ctx, const KeyPoint* kps, int cap, const int* start, int batch, int maxCount, int W, int H, int* hist, int* perm);
 int bhip_assoc_phase1_l2(bhip_ctx* ctx, const double* src, int nsLocal, int srcBegin, const double* dst, int nd, int dof, double maxErr, int sqrtScore,
 						 int* pairs, double* fit, void* colTop, DevBuf& work);
 int bhip_assoc_phase1_ham(bhip_ctx* ctx, const int32_t* src, int nsLocal, int srcBegin, const int32_t* dst, int nd, int words, double maxErr, int* pairs,
@@ -350,7 +351,7 @@ struct bhip_surf {
 	bhip_ori_cfg ori;
 	FhDetector det;
 	SurfTables tables;
-	DevBuf tabBuf, inBuf, iiBuf, startBuf, angBuf, descBuf, whiteBuf, xysBuf, tmpKp, tmpAng, tmpDesc, tmpWhite;
+	DevBuf tabBuf, inBuf, iiBuf, startBuf, angBuf, descBuf, whiteBuf, xysBuf, tmpKp, tmpAng, tmpDesc, tmpWhite, permBuf;
 	std::vector<int> starts;  // batch+1
 	int W = 0, H = 0, batch = 0;
 	bool haveResult = false;
@@ -438,8 +439,23 @@ static int surfRun(bhip_surf* s, ImgView in, int batch) {
 	BHIP_TRY(s->angBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8));
 	BHIP_TRY(s->descBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8 * dof));
 	BHIP_TRY(s->whiteBuf.reserve(ctx, (size_t)std::max<long long>(total, 1)));
+	// processing order of the describe stage: key points of one image grouped by coarse tile (L2 locality of the gathers)
+	const int* perm = nullptr;
+	{
+		static int noOrder = -1;
+		if (noOrder < 0) { const char* e = getenv("BHIP_DESCRIBE_NOORDER"); noOrder = (e && e[0] == '1') ? 1 : 0; }
+		int maxCount = 0;
+		for (int c : s->det.counts) maxCount = std::max(maxCount, c);
+		if (!noOrder && total > 0) {
+			BHIP_TRY(s->permBuf.reserve(ctx, (size_t)total * 4 + (size_t)batch * 64 * 4));
+			int* hist = s->permBuf.as<int>() + total;
+			BHIP_TRY(bhip_launch_kp_spatial_order(ctx, s->det.sorted.as<KeyPoint>(), s->det.cap, s->startBuf.as<int>(), batch, maxCount, W, H, hist,
+												  s->permBuf.as<int>()));
+			perm = s->permBuf.as<int>();
+		}
+	}
 	BHIP_TRY(bhip_launch_describe_ex(ctx, ii, s->det.sorted.as<KeyPoint>(), s->det.cap, s->startBuf.as<int>(), batch, 0, total, s->tables, nullptr,
-									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>()));
+									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>(), perm));
 	// the host vector `starts` was handed to an async copy: make sure it is consumed before it can change
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	s->haveResult = true;
@@ -469,7 +485,7 @@ int bhip_surf_destroy(bhip_surf* s) {
 	(void)hipSetDevice(s->ctx->device);
 	(void)hipStreamSynchronize(s->ctx->stream);
 	s->det.release();
-	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite};
+	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite, &s->permBuf};
 	for (DevBuf* b : bufs) b->release();
 	delete s;
 	return BHIP_OK;

@@ -38,6 +38,7 @@ struct DescParams {
 	double* angles;           // [total]
 	double* desc;             // [total][dof]
 	uint8_t* white;           // [total]
+	const int* perm;          // optional processing order: slot -> key point index
 	int ldsPerWave;           // bytes
 	unsigned long long* stamps; // diagnostic build only: [total][8] cycle stamps
 	int sort64;               // BHIP_DESCRIBE_SORT64=1: always sort on the fp64 keys (cross-check of the 32-bit key sort)
@@ -567,8 +568,9 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const long long chunk = (nblk + 7) >> 3;
 	const long long blk = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
 	if ((long long)(blockIdx.x >> 3) >= chunk) return;
-	const long long g = blk * 4 + wave;
-	if (g >= P.total) return;
+	const long long slot = blk * 4 + wave;
+	if (slot >= P.total) return;
+	const long long g = P.perm ? (long long)P.perm[slot] : slot;   // processing order (detect.hip, k_kp_tile_*); results stay at index g
 	unsigned char* lds = ldsAll + (size_t)wave * P.ldsPerWave;
 
 	// which image does key point g belong to?
@@ -868,11 +870,11 @@ int bhip_describe_lds_bytes(const SurfTables& t) {
 }
 
 int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int cap, const int* imageStart, int batch, int singleImage, long long total,
-							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white) {
+							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white, const int* perm) {
 	if (total <= 0) return BHIP_OK;
 	DescParams P;
 	P.ii = ii; P.kps = kps; P.cap = cap; P.imageStart = imageStart; P.batch = batch; P.singleImage = singleImage; P.total = total; P.t = t;
-	P.anglesIn = anglesIn; P.angles = angles; P.desc = desc; P.white = white;
+	P.anglesIn = anglesIn; P.angles = angles; P.desc = desc; P.white = white; P.perm = perm;
 	P.ldsPerWave = bhip_describe_lds_bytes(t);
 	P.stamps = nullptr;
 	{ const char* e = getenv("BHIP_DESCRIBE_SERIAL"); P.serialOnly = (e && e[0] == '1') ? 1 : 0; }

@@ -281,3 +281,59 @@ int bhip_launch_bitmap_to_xy(bhip_ctx* ctx, const float* img, int stride, int w,
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Processing order for the describe stage.  Results stay in detection order; only the order in which key points are WORKED ON changes:
+// image-major, then by coarse image tile (KPT x KPT tiles per image, raster), so the key points in flight on one XCD gather from one
+// compact part of the integral image and their taps hit that XCD's L2.  perm[slot] = compact index of the key point handled by slot.
+// ---------------------------------------------------------------------------------------------------------------
+#define KPT 8
+__global__ __launch_bounds__(256) void k_kp_tile_count(const KeyPoint* __restrict__ kps, int cap, const int* __restrict__ start, int W, int H,
+													   int* __restrict__ hist) {
+	const int img = blockIdx.y;
+	const int n = start[img + 1] - start[img];
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const KeyPoint kp = kps[(long long)img * cap + i];
+	const int tx = min(KPT - 1, max(0, (int)(kp.x * KPT / W))), ty = min(KPT - 1, max(0, (int)(kp.y * KPT / H)));
+	atomicAdd(&hist[img * (KPT * KPT) + ty * KPT + tx], 1);
+}
+// one wave per image: exclusive scan of the 64 tile counts (KPT*KPT == 64), in place
+__global__ __launch_bounds__(64) void k_kp_tile_scan(int* __restrict__ hist) {
+	const int img = blockIdx.x, lane = threadIdx.x;
+	const int c = hist[img * 64 + lane];
+	int sc = c;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int t = __shfl_up(sc, o, 64);
+		if (lane >= o) sc += t;
+	}
+	hist[img * 64 + lane] = sc - c;
+}
+__global__ __launch_bounds__(256) void k_kp_tile_scatter(const KeyPoint* __restrict__ kps, int cap, const int* __restrict__ start, int W, int H,
+														 int* __restrict__ cursor, int* __restrict__ perm) {
+	const int img = blockIdx.y;
+	const int s0 = start[img];
+	const int n = start[img + 1] - s0;
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const KeyPoint kp = kps[(long long)img * cap + i];
+	const int tx = min(KPT - 1, max(0, (int)(kp.x * KPT / W))), ty = min(KPT - 1, max(0, (int)(kp.y * KPT / H)));
+	const int pos = atomicAdd(&cursor[img * (KPT * KPT) + ty * KPT + tx], 1);
+	perm[s0 + pos] = s0 + i;
+}
+
+int bhip_launch_kp_spatial_order(bhip_ctx* ctx, const KeyPoint* kps, int cap, const int* start, int batch, int maxCount, int W, int H, int* hist /*batch*64*/,
+								 int* perm) {
+	if (batch <= 0 || maxCount <= 0) return BHIP_OK;
+	static_assert(KPT * KPT == 64, "k_kp_tile_scan assumes 64 tiles");
+	BHIP_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)batch * 64 * 4, ctx->stream));
+	ProfScope ps(ctx, "k_kp_spatial_order", 0);
+	dim3 grid((maxCount + 255) / 256, batch);
+	hipLaunchKernelGGL(k_kp_tile_count, grid, dim3(256), 0, ctx->stream, kps, cap, start, W, H, hist);
+	hipLaunchKernelGGL(k_kp_tile_scan, dim3(batch), dim3(64), 0, ctx->stream, hist);
+	hipLaunchKernelGGL(k_kp_tile_scatter, grid, dim3(256), 0, ctx->stream, kps, cap, start, W, H, hist, perm);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
