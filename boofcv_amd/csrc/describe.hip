@@ -276,48 +276,46 @@ __device__ __forceinline__ bool sortSamplesFast32(const float* gX, const float* 
 	waveSync();
 	unsigned int* srcK = keyA; unsigned int* dstK = keyB;
 	unsigned short* srcI = idxA; unsigned short* dstI = idxB;
+	// Merge rounds by merge path: a lane owns EPL consecutive OUTPUT slots of its pair of runs, finds where its diagonal cuts the two
+	// runs with ONE binary search, and merges its EPL outputs serially (A before B on ties = stable).  About a third of the
+	// instructions of one binary search per element.
 	for (int L = EPL; L < n; L <<= 1) {
-		unsigned int key[EPLT], keyCmp[EPLT];
-		int lo[EPLT], hi[EPLT], base[EPLT];
-#pragma unroll
-		for (int e = 0; e < EPLT; e++) {
-			const int p = p0 + e;
-			const int q = p / L;
-			const int runStart = q * L;
-			const bool right = q & 1;
-			const int sibStart = right ? runStart - L : runStart + L;
-			lo[e] = min(sibStart, n);
-			hi[e] = min(sibStart + L, n);
-			key[e] = e < cnt ? srcK[p] : 0u;
-			// elements of the left run go before equal elements of the right run (stable): a left element counts the siblings
-			// strictly below it, a right element those below or equal, i.e. strictly below key + 1 (keys never reach 0xffffffff)
-			keyCmp[e] = key[e] + (right ? 1u : 0u);
-			base[e] = (right ? sibStart : runStart) + (p - runStart) - min(sibStart, n);
-			if (e >= cnt) hi[e] = lo[e];
-		}
+		const int s = (p0 / (2 * L)) * (2 * L);
+		const int a0 = s, b0 = s + L;
+		const int lenA = cnt > 0 ? min(L, n - s) : 0;
+		const int lenB = cnt > 0 ? max(0, min(L, n - b0)) : 0;
+		const int d = p0 - s;
+		int lo = max(0, d - lenB), hi = min(d, lenA);
 		for (int span = L; span > 0; span >>= 1) {
-			unsigned int v[EPLT];
-#pragma unroll
-			for (int e = 0; e < EPLT; e++) {
-				const int mid = (lo[e] + hi[e]) >> 1;
-				v[e] = lo[e] < hi[e] ? srcK[mid] : 0u;
-			}
-#pragma unroll
-			for (int e = 0; e < EPLT; e++) {
-				if (lo[e] < hi[e]) {
-					const int mid = (lo[e] + hi[e]) >> 1;
-					if (v[e] < keyCmp[e]) lo[e] = mid + 1; else hi[e] = mid;
-				}
-			}
+			const int mid = (lo + hi) >> 1;
+			const bool on = lo < hi;
+			const unsigned int ka = on ? srcK[a0 + mid] : 0u;
+			const unsigned int kb = on ? srcK[b0 + d - 1 - mid] : 0u;
+			if (on) { if (ka <= kb) lo = mid + 1; else hi = mid; }
 		}
+		int i = lo, j = d - lo;
+		unsigned int ka = i < lenA ? srcK[a0 + i] : 0xffffffffu;
+		unsigned int kb = j < lenB ? srcK[b0 + j] : 0xffffffffu;
+		unsigned int outK[EPLT];
+		int sp[EPLT];
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
-			if (e < cnt) {
-				const int dst = base[e] + lo[e];
-				dstK[dst] = key[e];
-				dstI[dst] = srcI[p0 + e];
-			}
+			const bool takeA = ka <= kb;   // an exhausted run shows the sentinel; real keys are below it
+			outK[e] = takeA ? ka : kb;
+			sp[e] = takeA ? a0 + i : b0 + j;
+			i += takeA ? 1 : 0;
+			j += takeA ? 0 : 1;
+			const int nxt = takeA ? a0 + i : b0 + j;
+			const int lim = takeA ? a0 + lenA : b0 + lenB;
+			const unsigned int nk = (e + 1 < EPLT && nxt < lim) ? srcK[nxt] : 0xffffffffu;
+			if (takeA) ka = nk; else kb = nk;
 		}
+		unsigned short outI[EPLT];
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) outI[e] = e < cnt ? srcI[sp[e]] : (unsigned short)0;
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (e < cnt) { dstK[p0 + e] = outK[e]; dstI[p0 + e] = outI[e]; }
 		waveSync();
 		unsigned int* tk = srcK; srcK = dstK; dstK = tk;
 		unsigned short* ti = srcI; srcI = dstI; dstI = ti;
