@@ -40,7 +40,7 @@ struct DescParams {
 	uint8_t* white;           // [total]
 	const int* perm;          // optional processing order: slot -> key point index
 	int ldsPerWave;           // bytes
-	unsigned long long* stamps; // diagnostic build only: [total][8] cycle stamps
+	unsigned long long* stamps; // diagnostic build only: [total][16] cycle stamps
 	int sort64;               // BHIP_DESCRIBE_SORT64=1: always sort on the fp64 keys (cross-check of the 32-bit key sort)
 	int serialOnly;           // BHIP_DESCRIBE_SERIAL=1: always run the reference's serial window sweep (cross-check of the parallel form)
 };
@@ -125,6 +125,7 @@ __device__ __forceinline__ void waveSync() {
 // 4-byte gradients have to live through the sort.
 struct OriSortOut {
 	double* dX; double* dY; double* sA;
+	float* sF;   // (float)sA, for the coarse window searches
 };
 template <int EPLT>
 __device__ __forceinline__ void permuteSorted(const float* gX, const float* gY, const unsigned short* srcI, const double (&a)[EPLT], const double* weights,
@@ -142,7 +143,7 @@ __device__ __forceinline__ void permuteSorted(const float* gX, const float* gY, 
 	waveSync();
 #pragma unroll
 	for (int e = 0; e < EPLT; e++)
-		if (e < cnt) { o.dX[p0 + e] = x[e]; o.dY[p0 + e] = y[e]; o.sA[p0 + e] = a[e]; }
+		if (e < cnt) { o.dX[p0 + e] = x[e]; o.dY[p0 + e] = y[e]; o.sA[p0 + e] = a[e]; o.sF[p0 + e] = (float)a[e]; }
 	waveSync();
 }
 
@@ -361,8 +362,9 @@ __device__ __forceinline__ bool sortSamplesFast32(const float* gX, const float* 
 // The full-circle regime (some window wraps all the way round: ramps, flat patches) is detected and left to the serial code.
 // Returns false when the caller must run the serial sweep (the arrays are then still the sorted samples).
 template <int EPLT>
-__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, int* Esched, int n, double window, int lane, double& bestX,
-												   double& bestY) {
+__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, const float* sF, int* Esched, int n, double window, int lane,
+												   double& bestX, double& bestY, unsigned long long* st /*diagnostic stamps or nullptr*/) {
+#define WSTAMP(i) do { if (st && lane == 0) st[i] = __builtin_readcyclecounter(); } while (0)
 	const int EPL = (n + 63) >> 6;   // <= EPLT
 	const int p0 = lane * EPL;
 	const int cnt = max(0, min(EPL, n - p0));
@@ -370,38 +372,44 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 	int valE[EPLT];   // a + c(a) + 1
 	int runMax = 0;
 	{
-		// c(a): largest t with "successor t is on the leading side and inside the window"; all searches of this lane in lock step
-		double ta[EPLT];
+		// c(a): largest t such that every successor 1..t is on the leading side and inside the window.  Coarse part: binary search on
+		// the fp32 copies for the largest t that is inside by a margin (forward offset <= window - 4e-6; the fp32 offset is within
+		// 1.4e-6 of the exact one, so everything up to there passes the exact test as well).  Exact part: the reference's own test
+		// (UtilAngle.dist on the fp64 angles) walks on from there -- normally it fails at once.
+		const float winLo = (float)window - 4.0e-6f;
+		const float twoPiF = 6.28318530717958647692f;
+		if (!(winLo > 0.0f)) return false;
+		float fa[EPLT];
 		int lo[EPLT], hi[EPLT];
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
-			ta[e] = e < cnt ? sA[p0 + e] : 0.0;
+			fa[e] = e < cnt ? sF[p0 + e] : 0.0f;
 			lo[e] = 0;
 			hi[e] = e < cnt ? n : 1;
 		}
 		for (int span = n; span > 1; span = (span + 1) >> 1) {
-			double tk[EPLT];
+			float fk[EPLT];
 #pragma unroll
 			for (int e = 0; e < EPLT; e++) {
 				const int mid = (lo[e] + hi[e]) >> 1;
 				const int kabs = p0 + e + mid;
 				const int k = kabs >= n ? kabs - n : kabs;
-				tk[e] = (hi[e] - lo[e] > 1) ? sA[k] : 0.0;
+				fk[e] = (hi[e] - lo[e] > 1) ? sF[k] : 0.0f;
 			}
 #pragma unroll
 			for (int e = 0; e < EPLT; e++) {
 				if (hi[e] - lo[e] > 1) {
 					const int mid = (lo[e] + hi[e]) >> 1;
 					const int kabs = p0 + e + mid;
-					const double fo = (tk[e] - ta[e]) + (kabs >= n ? 2.0 * M_PI : 0.0);
-					const bool ok = fo < M_PI && angleDist(ta[e], tk[e]) <= window;
-					if (ok) lo[e] = mid; else hi[e] = mid;
+					const float fo = (fk[e] - fa[e]) + (kabs >= n ? twoPiF : 0.0f);
+					if (fo <= winLo) lo[e] = mid; else hi[e] = mid;
 				}
 			}
 		}
-		double nxt[EPLT];
+		double ta[EPLT], nxt[EPLT];
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
+			ta[e] = e < cnt ? sA[p0 + e] : 0.0;
 			const int kabs = p0 + e + lo[e] + 1;
 			const int k = kabs >= n ? kabs - n : kabs;
 			nxt[e] = (e < cnt && lo[e] < n - 1) ? sA[k] : 0.0;
@@ -410,15 +418,25 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 		for (int e = 0; e < EPLT; e++) {
 			valE[e] = 0;
 			if (e < cnt) {
-				const int c = lo[e];
+				int c = lo[e];
+				// exact continuation; a handful of steps at most unless many samples sit within 1e-5 of the window edge
+				int guard = 0;
+				while (c < n - 1) {
+					const int kabs = p0 + e + c + 1;
+					const double fo = (nxt[e] - ta[e]) + (kabs >= n ? 2.0 * M_PI : 0.0);
+					if (!(fo < M_PI && angleDist(ta[e], nxt[e]) <= window)) break;
+					c++;
+					if (++guard > 16) { abnormal = true; break; }
+					const int k2abs = p0 + e + c + 1;
+					nxt[e] = c < n - 1 ? sA[k2abs >= n ? k2abs - n : k2abs] : 0.0;
+				}
 				if (c >= n - 1) abnormal = true;
-				// the reference stops at the first successor that fails its test; make sure that really is successor c+1
-				else if (angleDist(ta[e], nxt[e]) <= window) abnormal = true;
 				valE[e] = p0 + e + c + 1;
 				runMax = max(runMax, valE[e]);
 			}
 		}
 	}
+	WSTAMP(8);
 	// inclusive max-scan of the per-lane maxima, then the exclusive value for this lane (E(-1) = 1)
 	int scan = runMax;
 #pragma unroll
@@ -460,6 +478,7 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 	}
 	if (__any(abnormal)) return false;
 	lastE = __shfl(lastE, (n - 1) / EPL, 64);  // E(n-1): one past the last end position that is ever tested
+	WSTAMP(9);
 	// ---- inclusive prefix sums of (dX, dY) in sorted order, in place: window sum(a..E) = I[E] - I[a-1]
 	{
 		double lx[EPLT], ly[EPLT], vx[EPLT], vy[EPLT];
@@ -488,54 +507,48 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 	}
 	waveSync();
 	const double totX = dX[n - 1], totY = dY[n - 1];
-	// ---- candidate windows, one per end position E in [1, E(n-1)), EPLT of them per lane at a time
+	WSTAMP(10);
+	// ---- candidate windows, one per end position E in [1, E(n-1))
 	double bMag = -1.0, bX = 0, bY = 0;
 	int bPos = 0x7fffffff;
 	if (lane == 0) { bX = dX[0]; bY = dY[0]; bMag = bX * bX + bY * bY; bPos = 0; }
-	for (int E0 = 1 + lane * EPLT; E0 < lastE; E0 += 64 * EPLT) {
-		int lo[EPLT], hi[EPLT];
-#pragma unroll
-		for (int e = 0; e < EPLT; e++) {
-			const int E = E0 + e;
-			lo[e] = 0;
-			hi[e] = E < lastE ? min(E, n - 1) : 0;   // owner is in [0, min(E, n-1)]: E(a) > a always
-		}
+	// Owner of end position E: a(E) = min{a : Esched[a] > E} within [0, min(E, n-1)] (Esched[a] > a always, so the cap is a <= n-1).
+	// Walking E upwards while a follows is a merge of two sorted lists -- A = Esched[0..n-2], B = the end positions 1..lastE-1, A first on
+	// ties -- in which every B step is one candidate window (E, a).  Merge path deals the lenA + lenB steps out evenly: a lane finds its
+	// diagonal with one binary search and then takes S steps, so no lane is held up by a long run of owners.
+	{
+		const int lenA = n - 1, lenB = lastE - 1;
+		const int tot = lenA + lenB;
+		const int S = (tot + 63) >> 6;
+		const int d = min(lane * S, tot);
+		int l0 = max(0, d - lenB), h0 = min(d, lenA);
 		for (int span = n; span > 0; span >>= 1) {
-			int ev[EPLT];
-#pragma unroll
-			for (int e = 0; e < EPLT; e++) ev[e] = lo[e] < hi[e] ? Esched[(lo[e] + hi[e]) >> 1] : 0;
-#pragma unroll
-			for (int e = 0; e < EPLT; e++) {
-				if (lo[e] < hi[e]) {
-					const int mid = (lo[e] + hi[e]) >> 1;
-					if (ev[e] > E0 + e) hi[e] = mid; else lo[e] = mid + 1;
-				}
-			}
+			const bool on = l0 < h0;
+			const int mid = (l0 + h0) >> 1;
+			const int ev = on ? Esched[mid] : 0;
+			if (on) { if (ev <= d - mid) l0 = mid + 1; else h0 = mid; }   // B[d-1-mid] = d - mid
 		}
-		double ax[EPLT], ay[EPLT], ex[EPLT], ey[EPLT];
-#pragma unroll
-		for (int e = 0; e < EPLT; e++) {
-			const int E = E0 + e;
-			const bool on = E < lastE;
-			const int a = lo[e];
-			const int ke = E >= n ? E - n : E;
-			ax[e] = (on && a > 0) ? dX[a - 1] : 0.0;
-			ay[e] = (on && a > 0) ? dY[a - 1] : 0.0;
-			ex[e] = on ? dX[ke] : 0.0;
-			ey[e] = on ? dY[ke] : 0.0;
-		}
-#pragma unroll
-		for (int e = 0; e < EPLT; e++) {
-			const int E = E0 + e;
-			if (E < lastE) {
+		int a = l0, j = d - l0;
+		int aKey = a < lenA ? Esched[a] : 0x7fffffff;
+		for (int st = 0; st < S; st++) {
+			const bool live = a + j < tot;
+			const int E = j + 1;
+			const bool takeA = aKey <= (j < lenB ? E : 0x7fffffff);
+			if (live && !takeA) {
+				const int ke = E >= n ? E - n : E;
+				const double ax = a > 0 ? dX[a - 1] : 0.0, ay = a > 0 ? dY[a - 1] : 0.0;
+				const double ex = dX[ke], ey = dY[ke];
 				double sx, sy;
-				if (E < n) { sx = ex[e] - ax[e]; sy = ey[e] - ay[e]; }
-				else { sx = (totX - ax[e]) + ex[e]; sy = (totY - ay[e]) + ey[e]; }
+				if (E < n) { sx = ex - ax; sy = ey - ay; }
+				else { sx = (totX - ax) + ex; sy = (totY - ay) + ey; }
 				const double mag = sx * sx + sy * sy;
 				if (mag > bMag) { bMag = mag; bX = sx; bY = sy; bPos = E; }   // E increases within a lane: strict > keeps the first
 			}
+			if (takeA) { a++; aKey = a < lenA ? Esched[a] : 0x7fffffff; }
+			else j++;
 		}
 	}
+	WSTAMP(11);
 	// ---- first maximum in sweep order across the wave: max magnitude, then the smallest position among the lanes that hold it
 	double m = bMag;
 #pragma unroll
@@ -547,12 +560,14 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 	const int src = __ffsll((long long)owner) - 1;
 	bestX = __shfl(bX, src, 64);
 	bestY = __shfl(bY, src, 64);
+	WSTAMP(12);
 	return true;
+#undef WSTAMP
 }
 
 // STAMP = true is a diagnostic build (BHIP_DESCRIBE_STAMPS): lane 0 of every wave records the cycle counter at the phase boundaries
 // into a buffer nothing else reads; never used for results or for quoted run times.
-#define DSTAMP(i) do { if (STAMP && lane == 0) P.stamps[g * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define DSTAMP(i) do { if (STAMP && lane == 0) P.stamps[g * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 
 // EPLT = orientation samples per lane = ceil(n / 64), TWT = samples per sub-region row: compile-time for the common configurations so
 // the unrolled batches carry no dead slots (the kernel is issue bound); <8,16> is the generic instantiation.
@@ -662,14 +677,14 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			double bestX = 0, bestY = 0;
 			bool needSerial = true;
 			// n <= 64 * EPLT is enforced on the host
-			const OriSortOut so{dX, dY, dY + n};
+			const OriSortOut so{dX, dY, dY + n, (float*)(lds + (size_t)28 * n)};
 			const double* wts = T.oriHasWeights ? T.oriWeights : nullptr;
 			bool sorted = false;
 			if (!P.sort64) sorted = sortSamplesFast32<EPLT>(gX, gY, ang, (unsigned int*)keyB, (unsigned int*)keyB + n, idxA, idxB, wts, so, n, lane);
 			if (!sorted) sortSamplesByAngle<EPLT>(gX, gY, ang, keyB, idxA, idxB, wts, so, n, lane);
 			ang = so.sA;   // sorted angles; dX, dY hold the sorted samples
 			DSTAMP(2);
-			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY);
+			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
 			if (needSerial) {
 				// estimateAngle() exactly as written in the reference, on the arrays already in sorted order (order[k] == k).
 				// Reached for the full-circle regime (all gradients within one window of each other: ramps, flat patches).
@@ -858,7 +873,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 
 int bhip_describe_lds_bytes(const SurfTables& t) {
 	const int n = t.oriWidth * t.oriWidth;
-	const int ori = n * 28 + 16;  // see sortSamplesByAngle: fp32 gradients + fp64 angles + key scratch + two u16 index buffers
+	const int ori = n * 32 + 16;  // see sortSamplesByAngle: 28n while sorting; dX dY sA Esched + the fp32 copy of the sorted angles afterwards
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
@@ -886,7 +901,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	if (stampPath && total > 1000) {
 		// diagnostic build: phase shares of the describe kernel (never a quoted run time)
 		unsigned long long* dev = nullptr;
-		if (hipMalloc(&dev, (size_t)total * 64) == hipSuccess) {
+		if (hipMalloc(&dev, (size_t)total * 128) == hipSuccess) {
 			(void)hipMemsetAsync(dev, 0, (size_t)total * 64, ctx->stream);
 			P.stamps = dev;
 			{
@@ -895,15 +910,16 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 				if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<true, 5, 9>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 				else hipLaunchKernelGGL((k_describe<true, 8, 16>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 			}
-			std::vector<unsigned long long> h((size_t)total * 8);
+			std::vector<unsigned long long> h((size_t)total * 16);
 			(void)hipMemcpy(h.data(), dev, (size_t)total * 64, hipMemcpyDeviceToHost);
 			(void)hipFree(dev);
-			double sum[7] = {0};
+			double sum[7] = {0}, wsum[6] = {0};
 			long long cnt = 0;
 			for (long long k = 0; k < total; k++) {
-				const unsigned long long* tt = &h[(size_t)k * 8];
+				const unsigned long long* tt = &h[(size_t)k * 16];
 				if (!tt[6] || !tt[0]) continue;
 				for (int i = 1; i <= 6; i++) sum[i] += (double)(tt[i] - tt[i - 1]);
+				if (tt[8] && tt[12]) { wsum[0] += (double)(tt[8] - tt[2]); for (int i = 1; i <= 4; i++) wsum[i] += (double)(tt[8 + i] - tt[7 + i]); wsum[5] += (double)(tt[3] - tt[12]); }
 				cnt++;
 			}
 			FILE* f = fopen(stampPath, "a");
@@ -911,6 +927,8 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 				fprintf(f, "waves %lld  avg cycles: samples %.0f  sort %.0f  window+atan2 %.0f  descSamples %.0f  sums %.0f  norm+laplace %.0f\n", cnt,
 						sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt);
 			}
+			if (f && cnt) fprintf(f, "   window split: c(a) %.0f  scan+validate %.0f  prefix %.0f  candidates %.0f  reduce %.0f  atan2+rest %.0f\n", wsum[0] / cnt, wsum[1] / cnt,
+								  wsum[2] / cnt, wsum[3] / cnt, wsum[4] / cnt, wsum[5] / cnt);
 			if (f) fclose(f);
 			BHIP_HIP(ctx, hipGetLastError());
 			return BHIP_OK;
