@@ -191,20 +191,30 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 		else rowV[g] = ok ? A.rowThr[P.rowBase + rr] : -INFINITY;
 	}
 
-	for (int c0 = B.col0; c0 < B.col1; c0 += 64) {
-		float b0[32], b1[32];
+	// B fragments are software-pipelined: the loads of step k+1 are issued before the MFMAs of step k, so their latency (an L2 /
+	// Infinity-Cache round trip, comparable to the 64 MFMAs of a step) overlaps the matrix work instead of preceding it
+	float b0[32], b1[32];
+	auto loadB = [&](int c0, float (&d0)[32], float (&d1)[32]) {
 		const int colA = c0 + r, colB = c0 + 32 + r;
 		const bool okA = colA < B.col1, okB = colB < B.col1;
-		{
-			const f32x4* s0 = (const f32x4*)(A.Fd + ((long long)(P.dstOff + (okA ? colA : 0)) * 64 + 32 * h));
-			const f32x4* s1 = (const f32x4*)(A.Fd + ((long long)(P.dstOff + (okB ? colB : 0)) * 64 + 32 * h));
+		const f32x4* s0 = (const f32x4*)(A.Fd + ((long long)(P.dstOff + (okA ? colA : 0)) * 64 + 32 * h));
+		const f32x4* s1 = (const f32x4*)(A.Fd + ((long long)(P.dstOff + (okB ? colB : 0)) * 64 + 32 * h));
 #pragma unroll
-			for (int q = 0; q < 8; q++) {
-				const f32x4 v = s0[q], w = s1[q];
-				b0[4 * q] = v.x; b0[4 * q + 1] = v.y; b0[4 * q + 2] = v.z; b0[4 * q + 3] = v.w;
-				b1[4 * q] = w.x; b1[4 * q + 1] = w.y; b1[4 * q + 2] = w.z; b1[4 * q + 3] = w.w;
-			}
+		for (int q = 0; q < 8; q++) {
+			const f32x4 v = s0[q], w = s1[q];
+			d0[4 * q] = v.x; d0[4 * q + 1] = v.y; d0[4 * q + 2] = v.z; d0[4 * q + 3] = v.w;
+			d1[4 * q] = w.x; d1[4 * q + 1] = w.y; d1[4 * q + 2] = w.z; d1[4 * q + 3] = w.w;
 		}
+	};
+	loadB(B.col0, b0, b1);
+	for (int c0 = B.col0; c0 < B.col1; c0 += 64) {
+		const int colA = c0 + r, colB = c0 + 32 + r;
+		const bool okA = colA < B.col1, okB = colB < B.col1;
+		// pass 1 has the registers to hold the next step's fragments; pass 2 (thresholds + candidate staging) does not and loads in place
+		float n0[PASS == 1 ? 32 : 1], n1[PASS == 1 ? 32 : 1];
+		const bool more = c0 + 64 < B.col1;   // wave-uniform
+		if constexpr (PASS == 1) { if (more) loadB(c0 + 64, n0, n1); }
+		else { if (c0 != B.col0) loadB(c0, b0, b1); }
 		const float nbA = okA ? A.nrmD[P.dstOff + colA] : INFINITY;
 		const float nbB = okB ? A.nrmD[P.dstOff + colB] : INFINITY;
 		f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -256,6 +266,12 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 					candPush(A, S, 1, dA <= tA, B.p, rr, colA, lane);
 					candPush(A, S, 1, dB <= tB, B.p, rr, colB, lane);
 				}
+			}
+		}
+		if constexpr (PASS == 1) {
+			if (more) {
+#pragma unroll
+				for (int q = 0; q < 32; q++) { b0[q] = n0[q]; b1[q] = n1[q]; }
 			}
 		}
 	}
