@@ -561,6 +561,102 @@ class AssociateDescription:
         return self.backwardsValidation
 
 
+class AssociateSurfBasic:
+    """F:alg/feature/associate/AssociateSurfBasic.java:36-170: SURF features are split by the sign of the Laplacian (BrightFeature.white)
+    and each sign is associated on its own -- features of different sign are never matched and each contraction is a quarter of the size."""
+
+    def __init__(self, assoc):
+        self.assoc = assoc
+        self._src = ([], [])   # (positive, negative) lists of (index, feature)
+        self._dst = ([], [])
+        self.matches = []
+        self.unassociatedSrc = []
+
+    @staticmethod
+    def _sort(features):
+        pos, neg = [], []
+        for i, f in enumerate(features):
+            (pos if f.white else neg).append((i, f))
+        return pos, neg
+
+    def setSrc(self, src):
+        self._src = self._sort(src)
+
+    def setDst(self, dst):
+        self._dst = self._sort(dst)
+
+    def swapLists(self):
+        self._src, self._dst = self._dst, self._src
+
+    def associate(self):
+        self.matches = []
+        self.unassociatedSrc = []
+        if not (self._src[0] or self._src[1]) or not (self._dst[0] or self._dst[1]):
+            return
+        for sign in (0, 1):   # positive, then negative
+            s, d = self._src[sign], self._dst[sign]
+            self.assoc.setSource([f for _, f in s])
+            self.assoc.setDestination([f for _, f in d])
+            self.assoc.associate()
+            for a in self.assoc.getMatches():
+                self.matches.append(AssociatedIndex(s[a.src][0], d[a.dst][0], a.fitScore))
+            self.unassociatedSrc.extend(s[i][0] for i in self.assoc.getUnassociatedSource())
+
+    def getMatches(self):
+        return self.matches
+
+    def totalDestination(self):
+        return len(self._dst[0]) + len(self._dst[1])
+
+    def getUnassociatedSrc(self):
+        return self.unassociatedSrc
+
+    def getAssoc(self):
+        return self.assoc
+
+
+class WrapAssociateSurfBasic:
+    """F:abst/feature/associate/WrapAssociateSurfBasic.java:33-101"""
+
+    def __init__(self, alg):
+        self.alg = alg
+
+    def setSource(self, listSrc):
+        self.alg.setSrc(listSrc)
+
+    def setDestination(self, listDst):
+        self.alg.setDst(listDst)
+
+    def associate(self):
+        self.alg.associate()
+
+    def getMatches(self):
+        return self.alg.getMatches()
+
+    def getUnassociatedSource(self):
+        return self.alg.getUnassociatedSrc()
+
+    def getUnassociatedDestination(self):
+        # FindUnassociated.checkDestination (F:alg/feature/associate/FindUnassociated.java:56-72)
+        n = self.alg.totalDestination()
+        matched = np.zeros(n, dtype=bool)
+        for m in self.alg.getMatches():
+            matched[m.dst] = True
+        return [i for i in range(n) if not matched[i]]
+
+    def setMaxScoreThreshold(self, score):
+        self.alg.getAssoc().setMaxScoreThreshold(score)
+
+    def getScoreType(self):
+        return self.alg.getAssoc().getScoreType()
+
+    def uniqueSource(self):
+        return self.alg.getAssoc().uniqueSource()
+
+    def uniqueDestination(self):
+        return self.alg.getAssoc().uniqueDestination()
+
+
 class FactoryAssociation:
     @staticmethod
     def greedy(score, maxError, backwardsValidation, ctx=None):

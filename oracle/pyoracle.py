@@ -309,6 +309,31 @@ def associate_l2(src, dst, maxErr=MAX_VALUE_F64, backwards=True, threads=1, sqrt
     return pairs, fit
 
 
+def associate_surf_basic(src, srcWhite, dst, dstWhite, maxErr=MAX_VALUE_F64, backwards=True, sqrt_score=False):
+    """AssociateSurfBasic.associate (F:alg/feature/associate/AssociateSurfBasic.java:83-124, sort :133-147): features are split by
+    Laplacian sign, each sign is associated on its own (positive first), matches carry the indices of the original lists.
+    Returns (matches [(src, dst, fitScore)], unassociatedSrc) in the reference's order."""
+    src = np.ascontiguousarray(src, dtype=np.float64); dst = np.ascontiguousarray(dst, dtype=np.float64)
+    sw = np.asarray(srcWhite, dtype=bool); dw = np.asarray(dstWhite, dtype=bool)
+    matches, unassoc = [], []
+    if len(src) == 0 or len(dst) == 0:
+        return matches, unassoc
+    for sign in (True, False):
+        si = np.flatnonzero(sw == sign); di = np.flatnonzero(dw == sign)
+        if len(si) == 0:
+            continue
+        if len(di) == 0:
+            # WrapAssociateGreedy on an empty destination list: nothing matches, every source is unassociated
+            unassoc.extend(int(i) for i in si)
+            continue
+        pairs, fit = associate_l2(src[si], dst[di], maxErr, backwards, 1, sqrt_score)
+        for k in range(len(si)):
+            if pairs[k] >= 0:
+                matches.append((int(si[k]), int(di[pairs[k]]), float(fit[k])))
+        unassoc.extend(int(si[k]) for k in range(len(si)) if pairs[k] < 0)
+    return matches, unassoc
+
+
 def associate_hamming(src, dst, maxErr=MAX_VALUE_F64, backwards=True, threads=1):
     """AssociateGreedy + ScoreAssociateHamming_B on int32 words."""
     src = np.ascontiguousarray(src, dtype=np.int32); dst = np.ascontiguousarray(dst, dtype=np.int32)

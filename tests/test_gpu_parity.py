@@ -654,6 +654,40 @@ def test_detector_plans_agree(api, orc, tmp_path):
         assert np.array_equal(np.load(out), base), env
 
 
+def test_associate_surf_basic(api, orc):
+    """AssociateSurfBasic / WrapAssociateSurfBasic (TestAssociateSurfBasic.java literals + detected SURF features of two noise images)."""
+    def feats(desc, white):
+        return [api.BrightFeature(64, np.asarray(d, dtype=np.float64), bool(w)) for d, w in zip(desc, white)]
+
+    def run(sd, sw, dd, dw, score, maxErr, backwards):
+        alg = api.WrapAssociateSurfBasic(api.AssociateSurfBasic(api.FactoryAssociation.greedy(score, maxErr, backwards)))
+        alg.setSource(feats(sd, sw)); alg.setDestination(feats(dd, dw)); alg.associate()
+        return [(m.src, m.dst, m.fitScore) for m in alg.getMatches()], list(alg.getUnassociatedSource()), list(alg.getUnassociatedDestination())
+
+    d = lambda vals: np.pad(np.asarray(vals, dtype=np.float64)[:, None], ((0, 0), (0, 63)))
+    eu = api.ScoreAssociateEuclidean_F64()
+    m, us, ud = run(d([10]), [True], d([0, 10]), [True, False], eu, 20, True)
+    assert [(a, b) for a, b, _ in m] == [(0, 0)] and us == [] and ud == [1]
+    sd, sw, dd, dw = d([10, 12, 5, 2344, 1000]), [True, True, False, False, False], d([0, 10.1, 13, 0.1, 7]), [True, True, True, False, False]
+    m, us, ud = run(sd, sw, dd, dw, eu, 20, True)
+    em, eus = orc.associate_surf_basic(sd, sw, dd, dw, 20, True, sqrt_score=True)
+    assert m == em and us == eus and [(a, b) for a, b, _ in m] == [(0, 1), (1, 2), (2, 4)]
+    assert run(np.zeros((0, 64)), [], d([10]), [True], eu, 20, True)[0] == []
+    # real features
+    dd_ = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32)
+    sets = []
+    for seed in (5, 6):
+        dd_.detect(G(api, orc.noise_image(240, 180, seed)))
+        n = dd_.getNumberOfFeatures()
+        sets.append((np.array([dd_.getDescription(i).value for i in range(n)]), [dd_.getDescription(i).white for i in range(n)]))
+    (a, aw), (b, bw) = sets
+    for backwards in (True, False):
+        m, us, ud = run(a, aw, b, bw, api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, backwards)
+        em, eus = orc.associate_surf_basic(a, aw, b, bw, orc.MAX_VALUE_F64, backwards)
+        assert m == em and us == eus and len(m) > 50
+        assert all(aw[i] == bw[j] for i, j, _ in m)
+
+
 def test_describe_internal_paths_agree(api, orc):
     """The 32-bit-key sort (with its fp64 check and fallback) must order exactly like the fp64 (angle, index) sort, and the parallel
     window enumeration must pick the reference's window: angles and descriptors with BHIP_DESCRIBE_SORT64 / BHIP_DESCRIBE_SERIAL are

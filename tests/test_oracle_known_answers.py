@@ -547,3 +547,26 @@ def test_pyramid_sigmas_and_odd_sizes(orc):  # TestPyramidDiscreteSampleBlur.jav
     layers, sig = orc.pyramid(ker, 3, [2, 4, 8], inp)
     assert sig[0] == 0 and abs(sig[1] - 6) < 1e-8
     assert [l.shape for l in layers] == [(14, 21), (7, 11), (4, 6)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# AssociateSurfBasic   FT:alg/feature/associate/TestAssociateSurfBasic.java
+# ---------------------------------------------------------------------------------------------------
+def _surf_desc(vals):
+    d = np.zeros((len(vals), 64))
+    d[:, 0] = vals
+    return d
+
+
+def test_associate_surf_basic_literals(orc):
+    # checkAssociateByIntensity :44-62: different Laplacian signs are never associated, even when the other sign fits better
+    m, un = orc.associate_surf_basic(_surf_desc([10]), [True], _surf_desc([0, 10]), [True, False], maxErr=20, backwards=True, sqrt_score=True)
+    assert len(m) == 1 and m[0][1] == 0 and un == []
+    # basicAssociation :64-109
+    m, un = orc.associate_surf_basic(_surf_desc([10, 12, 5, 2344, 1000]), [True, True, False, False, False],
+                                     _surf_desc([0, 10.1, 13, 0.1, 7]), [True, True, True, False, False], maxErr=20, backwards=True, sqrt_score=True)
+    assert [(a, b) for a, b, _ in m] == [(0, 1), (1, 2), (2, 4)] and all(f != 0 for _, _, f in m)
+    assert len(un) == 2 and not set(un) & {a for a, _, _ in m}
+    # handleEmptyLists :153-: empty source or destination gives no matches
+    assert orc.associate_surf_basic(_surf_desc([]), [], _surf_desc([10]), [True]) == ([], [])
+    assert orc.associate_surf_basic(_surf_desc([10]), [True], _surf_desc([]), []) == ([], [])
