@@ -17,10 +17,14 @@
 // outside the image) and the isInside test disappears.  The orientation angles are ordered by (angle, sample index): the
 // reference's ddogleg QuickSort_F64 is unstable and its tie order is not pinned by any reference test (SURVEY hard part 5).
 //
-// Structure: the kernel is latency bound (long chains of dependent LDS / L2 reads at 3-4 waves per SIMD), so every phase is written
-// to keep many independent loads in flight:
+// Structure: one wavefront per key point, four per workgroup; every phase keeps many independent loads in flight (the kernel is bound by
+// LDS / L2 round trips at 4 waves per SIMD, not by arithmetic):
 //   * gathers are branch-free (out-of-bounds samples read a safe address and are zeroed afterwards) and issued in unrolled batches;
-//   * the merge sort and the window searches advance all of a lane's binary searches in lock step;
+//     key points are worked on in coarse-tile order per image and XCD-chunked block order, so the taps of the waves in flight hit L2;
+//   * the 289 (angle, index) pairs are sorted by merge path on 32-bit keys with an fp64 check (fp64 merge sort as the fallback);
+//   * the sliding-window sweep is enumerated in parallel: c(a) by a coarse fp32 search + exact continuation, the end-pointer schedule by
+//     a max-scan, window sums as prefix-sum differences, the (end, owner) pairs by merge path; the reference's serial sweep handles the
+//     full-circle regime;
 //   * the 81-term sub-region sums keep the reference's sequential fp64 order per output but fetch a whole row of samples and
 //     weights per wait.
 #include "common.h"
@@ -86,17 +90,6 @@ __device__ __forceinline__ void gradSample(const float* __restrict__ d, const Gr
 	const float bottom = p6 - p9 - p5 + p10;
 	gx = inb ? right - left : 0.0f;
 	gy = inb ? bottom - top : 0.0f;
-}
-
-// ---- clamped box sum (ImplIntegralImageOps.block_zero) for the Laplacian sign ----
-__device__ __forceinline__ float blockZero(const float* __restrict__ d, int stride, int W, int H, int x0, int y0, int x1, int y1) {
-	x0 = min(x0, W - 1); y0 = min(y0, H - 1); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
-	float br = 0, tr = 0, bl = 0, tl = 0;
-	if (x1 >= 0 && y1 >= 0) br = d[(long long)y1 * stride + x1];
-	if (y0 >= 0 && x1 >= 0) tr = d[(long long)y0 * stride + x1];
-	if (x0 >= 0 && y1 >= 0) bl = d[(long long)y1 * stride + x0];
-	if (x0 >= 0 && y0 >= 0) tl = d[(long long)y0 * stride + x0];
-	return br - tr - bl + tl;
 }
 
 // georegression UtilAngle.dist: circular distance in [0,pi]
