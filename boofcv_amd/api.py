@@ -171,6 +171,38 @@ class TupleDesc_F64:
         self.value = np.array(src.value, dtype=np.float64)
 
 
+class Planar:
+    """T:struct/image/Planar.java: bands of one shape.  Planar(GrayF32, width, height, numBands) or Planar.wrap([bands])."""
+
+    def __init__(self, bandType=None, width=0, height=0, numBands=0):
+        if bandType is not None and bandType is not GrayF32:
+            raise RuntimeError("only GrayF32 bands are implemented on the GPU")
+        self.width, self.height = int(width), int(height)
+        self.bands = [GrayF32(width, height) for _ in range(numBands)]
+
+    @staticmethod
+    def wrap(bands):
+        p = Planar(GrayF32, bands[0].width, bands[0].height, 0)
+        for b in bands:
+            if b.width != p.width or b.height != p.height:
+                raise IllegalArgumentException("bands must have the same shape")
+        p.bands = list(bands)
+        return p
+
+    def getNumBands(self):
+        return len(self.bands)
+
+    def getBand(self, i):
+        return self.bands[i]
+
+
+class PlanarType:
+    """ImageType.pl(numBands, GrayF32.class)"""
+
+    def __init__(self, numBands, bandType=None):
+        self.numBands, self.bandType = int(numBands), bandType or GrayF32
+
+
 class BrightFeature(TupleDesc_F64):
     """F:struct/feature/BrightFeature.java:32: SURF descriptor + sign of the Laplacian."""
 
@@ -431,7 +463,52 @@ class DetectDescribePoint:
         return True
 
 
+class SurfPlanar_to_DetectDescribePoint(DetectDescribePoint):
+    """DetectDescribePoint<Planar<GrayF32>,BrightFeature> (F:abst/feature/detdesc/SurfPlanar_to_DetectDescribePoint.java:40-132 over
+    F:alg/feature/detdesc/DetectDescribeSurfPlanar.java and F:alg/feature/describe/DescribePointSurfPlanar.java): key points from the band
+    average, orientation with object radius = scale, one descriptor per band concatenated and normalised as a whole."""
+
+    def __init__(self, stable, configDetector, configDescribe, configOrientation, numBands, ctx=None):
+        super().__init__(stable, configDetector, configDescribe, configOrientation, ctx)
+        self.numBands = int(numBands)
+        self._dof = self._dof * self.numBands
+
+    def detect(self, input):
+        if input.getNumBands() != self.numBands:
+            raise IllegalArgumentException("Unexpected number of bands. Expected %d found %d" % (self.numBands, input.getNumBands()))
+        b0 = input.getBand(0)
+        for b in input.bands:
+            if (b.startIndex, b.stride) != (b0.startIndex, b0.stride):
+                raise IllegalArgumentException("bands must share startIndex and stride")   # Planar images do (ImageMultiBand layout)
+        ptrs = (C.POINTER(C.c_float) * self.numBands)(*[b._p() for b in input.bands])
+        self._cache = {}
+        self._batch = 0
+        _check(self.ctx, _lib.load().bhip_surf_detect_planar_f32(self._h, ptrs, self.numBands, b0.startIndex, b0.stride, input.width, input.height))
+        self._batch = 1
+        self._image = 0
+
+    def detectBatch(self, images):
+        raise RuntimeError("colour SURF processes one planar frame per call")
+
+    def getRadius(self, featureIndex):
+        return float(self._results()[0][featureIndex][2])   # DetectDescribeSurfPlanar.getRadius: the scale itself
+
+
 class FactoryDetectDescribe:
+    @staticmethod
+    def surfColorFast(configDetector=None, configDesc=None, configOrientation=None, imageType=None, ctx=None):
+        """F:factory/feature/detdesc/FactoryDetectDescribe.java:154-176"""
+        if not isinstance(imageType, PlanarType):
+            raise IllegalArgumentException("Image type not supported")
+        return SurfPlanar_to_DetectDescribePoint(False, configDetector, configDesc, configOrientation, imageType.numBands, ctx)
+
+    @staticmethod
+    def surfColorStable(configDetector=None, configDescribe=None, configOrientation=None, imageType=None, ctx=None):
+        """F:factory/feature/detdesc/FactoryDetectDescribe.java:246-268"""
+        if not isinstance(imageType, PlanarType):
+            raise IllegalArgumentException("Image type not supported")
+        return SurfPlanar_to_DetectDescribePoint(True, configDetector, configDescribe, configOrientation, imageType.numBands, ctx)
+
     @staticmethod
     def surfFast(configDetector=None, configDesc=None, configOrientation=None, imageType=GrayF32, ctx=None):
         if imageType is not GrayF32:

@@ -8,7 +8,7 @@
 
 // launchers defined in the other translation units
 int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int cap, const int* imageStart, int batch, int singleImage, long long total,
-							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white, const int* perm = nullptr);
+							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white, const int* perm = nullptr, const DescPlanar* planar = nullptr);
 int bhip_launch_kp_spatial_order(bhip_ctx* ctx, const KeyPoint* kps, int cap, const int* start, int batch, int maxCount, int W, int H, int* hist, int* perm);
 int bhip_assoc_phase1_l2(bhip_ctx* ctx, const double* src, int nsLocal, int srcBegin, const double* dst, int nd, int dof, double maxErr, int sqrtScore,
 						 int* pairs, double* fit, void* colTop, DevBuf& work);
@@ -20,6 +20,7 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 					 int height, float* out, int outStride);
 int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
 						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch);
+int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out);
 int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out);
@@ -356,6 +357,9 @@ struct bhip_surf {
 	int W = 0, H = 0, batch = 0;
 	bool haveResult = false;
 	ImgView iiView;
+	int planarBands = 0;       // > 0: the last detect was colour SURF on that many bands (descriptor = planarBands * dof values)
+	DescPlanar planar{};
+	int dofOut() const { return tables.dof * (planarBands > 0 ? planarBands : 1); }
 };
 
 static int buildTables(bhip_surf* s) {
@@ -416,17 +420,21 @@ static int buildTables(bhip_surf* s) {
 	return BHIP_OK;
 }
 
-static int surfRun(bhip_surf* s, ImgView in, int batch) {
+// planarBands > 0: `in` holds [1 + planarBands] images -- the band average first, then the bands (colour SURF, one frame)
+static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0) {
 	bhip_ctx* ctx = s->ctx;
 	const int W = in.width, H = in.height;
 	s->haveResult = false;
 	BHIP_TRY(s->det.prepare(ctx, W, H, batch));
-	BHIP_TRY(s->iiBuf.reserve(ctx, (size_t)W * H * 4 * batch));
+	const int nImages = planarBands > 0 ? 1 + planarBands : batch;
+	BHIP_TRY(s->iiBuf.reserve(ctx, (size_t)W * H * 4 * nImages));
 	s->W = W; s->H = H; s->batch = batch;
 	ImgViewW iiW{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
-	BHIP_TRY(bhip_launch_integral(ctx, in, iiW, batch));
+	BHIP_TRY(bhip_launch_integral(ctx, in, iiW, nImages));
 	ImgView ii{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
 	s->iiView = ii;
+	s->planarBands = planarBands;
+	s->planar = DescPlanar{s->iiBuf.as<float>() + (long long)W * H, (long long)W * H * (1 + planarBands), (long long)W * H, planarBands, 1.0};
 	BHIP_TRY(s->det.run(ctx, ii));
 	// exclusive prefix of counts -> start of every image in the compact result arrays
 	s->starts.assign(batch + 1, 0);
@@ -435,7 +443,7 @@ static int surfRun(bhip_surf* s, ImgView in, int batch) {
 	if (total > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_CAPACITY, "more than 2^31 key points in one batch");
 	BHIP_TRY(s->startBuf.reserve(ctx, (size_t)(batch + 1) * 4));
 	BHIP_HIP(ctx, hipMemcpyAsync(s->startBuf.p, s->starts.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-	const int dof = s->tables.dof;
+	const int dof = s->dofOut();
 	BHIP_TRY(s->angBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8));
 	BHIP_TRY(s->descBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8 * dof));
 	BHIP_TRY(s->whiteBuf.reserve(ctx, (size_t)std::max<long long>(total, 1)));
@@ -455,7 +463,7 @@ static int surfRun(bhip_surf* s, ImgView in, int batch) {
 		}
 	}
 	BHIP_TRY(bhip_launch_describe_ex(ctx, ii, s->det.sorted.as<KeyPoint>(), s->det.cap, s->startBuf.as<int>(), batch, 0, total, s->tables, nullptr,
-									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>(), perm));
+									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>(), perm, planarBands > 0 ? &s->planar : nullptr));
 	// the host vector `starts` was handed to an async copy: make sure it is consumed before it can change
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	s->haveResult = true;
@@ -491,7 +499,7 @@ int bhip_surf_destroy(bhip_surf* s) {
 	return BHIP_OK;
 }
 
-int bhip_surf_dof(bhip_surf* s) { return s ? s->tables.dof : 0; }
+int bhip_surf_dof(bhip_surf* s) { return s ? s->dofOut() : 0; }
 
 int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long imageStride, int stride, int width, int height, int batch) {
 	if (!s) return BHIP_ERR_INVALID;
@@ -520,6 +528,28 @@ int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* start
 	return surfRun(s, in, batch);
 }
 
+// FactoryDetectDescribe.surfColorStable / surfColorFast on one Planar<GrayF32> frame:
+//   SurfPlanar_to_DetectDescribePoint.detect      F:abst/feature/detdesc/SurfPlanar_to_DetectDescribePoint.java:62-77
+//   ImplConvertPlanarToGray.average               I:core/image/impl/ImplConvertPlanarToGray.java:296-336
+//   DetectDescribeSurfPlanar.detect / describe    F:alg/feature/detdesc/DetectDescribeSurfPlanar.java:91-124
+//   DescribePointSurfPlanar.describe              F:alg/feature/describe/DescribePointSurfPlanar.java:100-114
+int bhip_surf_detect_planar_f32(bhip_surf* s, const float* const* bands, int numBands, int startIndex, int stride, int width, int height) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!bands || numBands < 1 || numBands > 16 || width <= 0 || height <= 0 || stride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad planar image");
+	const size_t px = (size_t)width * height;
+	BHIP_TRY(s->inBuf.reserve(ctx, px * 4 * (1 + numBands)));
+	for (int b = 0; b < numBands; b++) {
+		if (!bands[b]) return bhip_fail(ctx, BHIP_ERR_INVALID, "null band");
+		BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + px * 4 * (1 + b), (size_t)width * 4, bands[b] + startIndex, (size_t)stride * 4, (size_t)width * 4, height,
+									   hipMemcpyHostToDevice, ctx->stream));
+	}
+	BHIP_TRY(bhip_launch_planar_average(ctx, s->inBuf.as<float>() + px, (long long)px, numBands, (long long)px, s->inBuf.as<float>()));
+	ImgView in{s->inBuf.as<float>(), (long long)px, width, width, height};
+	return surfRun(s, in, 1, numBands);
+}
+
 int bhip_surf_count(bhip_surf* s, int image, int* n) {
 	if (!s || !n) return BHIP_ERR_INVALID;
 	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
@@ -533,6 +563,7 @@ int bhip_surf_total(bhip_surf* s, long long* n) {
 }
 
 int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, uint8_t* white, double* desc) {
+	// (dof below is the full descriptor length: numBands * 64 after a planar detect)
 	if (!s) return BHIP_ERR_INVALID;
 	bhip_ctx* ctx = s->ctx;
 	CHECK_CTX(ctx);
@@ -540,7 +571,7 @@ int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, ui
 	const int n = s->det.counts[image];
 	if (n == 0) return BHIP_OK;
 	const long long off = s->starts[image];
-	const int dof = s->tables.dof;
+	const int dof = s->dofOut();
 	std::vector<KeyPoint> kps;
 	if (xy_scale) {
 		kps.resize(n);
@@ -560,7 +591,7 @@ int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const d
 	if (!s) return BHIP_ERR_INVALID;
 	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
 	const long long off = s->starts[image];
-	if (dev_desc) *dev_desc = s->descBuf.as<double>() + off * s->tables.dof;
+	if (dev_desc) *dev_desc = s->descBuf.as<double>() + off * s->dofOut();
 	// key points are KeyPoint records {x,y,scale,key,pad}: 32-byte stride, first three doubles are x,y,scale
 	if (dev_xy_scale) *dev_xy_scale = (const double*)(s->det.sorted.as<KeyPoint>() + (long long)image * s->det.cap);
 	if (dev_white) *dev_white = s->whiteBuf.as<uint8_t>() + off;
@@ -587,14 +618,14 @@ int bhip_surf_describe_points(bhip_surf* s, int image, const double* xy_scale, i
 	if (n == 0) return BHIP_OK;
 	std::vector<KeyPoint> kps(n);
 	for (int i = 0; i < n; i++) { kps[i].x = xy_scale[3 * i]; kps[i].y = xy_scale[3 * i + 1]; kps[i].scale = xy_scale[3 * i + 2]; kps[i].key = 0; kps[i].pad = 0; }
-	const int dof = s->tables.dof;
+	const int dof = s->dofOut();
 	BHIP_TRY(s->tmpKp.reserve(ctx, (size_t)n * sizeof(KeyPoint)));
 	BHIP_TRY(s->tmpAng.reserve(ctx, (size_t)n * 8));
 	BHIP_TRY(s->tmpDesc.reserve(ctx, (size_t)n * 8 * dof));
 	BHIP_TRY(s->tmpWhite.reserve(ctx, (size_t)n));
 	BHIP_HIP(ctx, hipMemcpyAsync(s->tmpKp.p, kps.data(), (size_t)n * sizeof(KeyPoint), hipMemcpyHostToDevice, ctx->stream));
 	BHIP_TRY(bhip_launch_describe_ex(ctx, s->iiView, s->tmpKp.as<KeyPoint>(), 0, nullptr, s->batch, image, n, s->tables, nullptr, s->tmpAng.as<double>(),
-									 s->tmpDesc.as<double>(), s->tmpWhite.as<uint8_t>()));
+									 s->tmpDesc.as<double>(), s->tmpWhite.as<uint8_t>(), nullptr, s->planarBands > 0 ? &s->planar : nullptr));
 	if (angle) BHIP_HIP(ctx, hipMemcpyAsync(angle, s->tmpAng.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
 	if (white) BHIP_HIP(ctx, hipMemcpyAsync(white, s->tmpWhite.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
 	if (desc) BHIP_HIP(ctx, hipMemcpyAsync(desc, s->tmpDesc.p, (size_t)n * 8 * dof, hipMemcpyDeviceToHost, ctx->stream));

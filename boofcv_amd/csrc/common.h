@@ -150,6 +150,13 @@ struct HessLevelSource {
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
 						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr);
 
+// colour SURF request for the describe kernel (see DescParams)
+struct DescPlanar {
+	const float* data;               // band integral images, [image][band][H][W]
+	long long imageStride, bandStride;
+	int nBands;
+	double oriRadiusFactor;
+};
 struct DetectLevelParams {
 	int skip, w, h;              // intensity image size
 	int sizeLower, sizeMid, sizeUpper;  // kernel sizes of level-1, level, level+1

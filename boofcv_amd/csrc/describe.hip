@@ -43,6 +43,14 @@ struct DescParams {
 	double* desc;             // [total][dof]
 	uint8_t* white;           // [total]
 	const int* perm;          // optional processing order: slot -> key point index
+	// colour SURF (DescribePointSurfPlanar): the descriptor is built band by band from these integral images ([image][band][H][W]),
+	// concatenated un-normalised and normalised once; orientation and Laplacian sign still come from `ii` (the grey integral image).
+	// nBands == 0: single-band descriptor from `ii`.
+	const float* bandData;
+	long long bandImageStride, bandStride;
+	int nBands;
+	double oriRadiusFactor;   // object radius of the orientation = scale * factor (2 = BoofDefaults.SURF_SCALE_TO_RADIUS in the grey
+	                          // wrapper, 1 in DetectDescribeSurfPlanar.describe)
 	int ldsPerWave;           // bytes
 	unsigned long long* stamps; // diagnostic build only: [total][16] cycle stamps
 	int sort64;               // BHIP_DESCRIBE_SORT64=1: always sort on the fp64 keys (cross-check of the 32-bit key sort)
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	if (P.anglesIn) {
 		angle = P.anglesIn[g];
 	} else {
-		const double radius = kp.scale * 2.0;                 // BoofDefaults.SURF_SCALE_TO_RADIUS
+		const double radius = kp.scale * P.oriRadiusFactor;
 		const double oscale = radius * T.oriRadiusToScale;    // setObjectRadius
 		const GradGeom G = makeGeom(gradRadius(oscale * T.oriKernelWidth), stride, W, H);
 		const double period = oscale * T.oriPeriod;
@@ -758,6 +766,11 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		const int cy = (corner == 0 || corner == 2) ? by1 : by0;
 		if (cx >= 0 && cy >= 0) lapTap = d[(long long)cy * stride + cx];
 	}
+	const int dof = T.dof;
+	const int nb = P.nBands > 0 ? P.nBands : 1;
+	for (int band = 0; band < nb; band++) {
+	const float* __restrict__ db = P.nBands > 0 ? P.bandData + (long long)img * P.bandImageStride + (long long)band * P.bandStride : d;
+	if (band > 0) waveSync();   // the previous band's sums have read sX, sY
 	{
 		// sample grid in 8x8 blocks: the 64 lanes of one pass cover a compact (8 scale)^2 patch of the image, so a wave-level gather
 		// touches a few dozen cache lines instead of up to 64.  The LDS layout stays [iy][ix].
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 					const double regionX = rX * scale;
 					const int pixelX = (int)(c_x + c * regionX - s * regionY);
 					const int pixelY = (int)(c_y + s * regionX + c * regionY);
-					gradSample(d, G, pixelX, pixelY, gx[u], gy[u]);
+					gradSample(db, G, pixelX, pixelY, gx[u], gy[u]);
 				}
 			}
 #pragma unroll
@@ -792,7 +805,6 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	}
 	waveSync();
 	DSTAMP(4);
-	const int dof = T.dof;
 	const int T_w = T.widthSubRegion + 2 * overLap;  // samples per sub-region side (<= TWT, enforced on the host)
 	for (int f = lane; f < dof; f += 64) {
 		const int sub = f >> 2, comp = f & 3;
@@ -826,22 +838,24 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			}
 		}
 		if (T.stable) sum = T.weightGrid[sub] * sum;
-		feat[f] = sum;
+		feat[band * dof + f] = sum;
 	}
+	}   // bands
 	waveSync();
 	DSTAMP(5);
 	// normalizeL2: sum of squares as a wave reduction (the reference adds the squares sequentially; the two orders differ by a few
 	// ulp of the norm, ~1e-16 relative on the descriptor, against the 1e-5 bar)
+	const int dofAll = dof * nb;
 	double norm = 0;
-	for (int f = lane; f < dof; f += 64) { const double v = feat[f]; norm += v * v; }
+	for (int f = lane; f < dofAll; f += 64) { const double v = feat[f]; norm += v * v; }
 #pragma unroll
 	for (int o = 32; o >= 1; o >>= 1) norm += __shfl_xor(norm, o, 64);
-	double* out = P.desc + g * dof;
+	double* out = P.desc + g * dofAll;
 	if (norm == 0) {
-		for (int f = lane; f < dof; f += 64) out[f] = feat[f];
+		for (int f = lane; f < dofAll; f += 64) out[f] = feat[f];
 	} else {
 		norm = sqrt(norm);
-		for (int f = lane; f < dof; f += 64) out[f] = feat[f] / norm;
+		for (int f = lane; f < dofAll; f += 64) out[f] = feat[f] / norm;
 	}
 	if (P.white) {
 		// block_zero = br - tr - bl + tl per box, then xx = 0 + b0*1 + b1*(-3), yy likewise, lap = (double)xx + (double)yy
@@ -864,24 +878,30 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	DSTAMP(6);
 }
 
-int bhip_describe_lds_bytes(const SurfTables& t) {
+int bhip_describe_lds_bytes(const SurfTables& t, int nBands) {
 	const int n = t.oriWidth * t.oriWidth;
 	const int ori = n * 32 + 16;  // see sortSamplesByAngle: 28n while sorting; dX dY sA Esched + the fp32 copy of the sorted angles afterwards
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
-	const int desc = (2 * ns + (ns & 1)) * 4 + t.dof * 8;
+	const int desc = (2 * ns + (ns & 1)) * 4 + t.dof * 8 * (nBands > 0 ? nBands : 1);
 	int b = ori > desc ? ori : desc;
 	return (b + 15) & ~15;
 }
 
 int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int cap, const int* imageStart, int batch, int singleImage, long long total,
-							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white, const int* perm) {
+							SurfTables t, const double* anglesIn, double* angles, double* desc, uint8_t* white, const int* perm, const DescPlanar* planar) {
 	if (total <= 0) return BHIP_OK;
 	DescParams P;
 	P.ii = ii; P.kps = kps; P.cap = cap; P.imageStart = imageStart; P.batch = batch; P.singleImage = singleImage; P.total = total; P.t = t;
 	P.anglesIn = anglesIn; P.angles = angles; P.desc = desc; P.white = white; P.perm = perm;
-	P.ldsPerWave = bhip_describe_lds_bytes(t);
+	P.bandData = nullptr; P.bandImageStride = P.bandStride = 0; P.nBands = 0; P.oriRadiusFactor = 2.0;
+	if (planar) {
+		if (planar->nBands < 1 || !planar->data) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad planar description request");
+		P.bandData = planar->data; P.bandImageStride = planar->imageStride; P.bandStride = planar->bandStride; P.nBands = planar->nBands;
+		P.oriRadiusFactor = planar->oriRadiusFactor;
+	}
+	P.ldsPerWave = bhip_describe_lds_bytes(t, P.nBands);
 	P.stamps = nullptr;
 	{ const char* e = getenv("BHIP_DESCRIBE_SERIAL"); P.serialOnly = (e && e[0] == '1') ? 1 : 0; }
 	{ const char* e = getenv("BHIP_DESCRIBE_SORT64"); P.sort64 = (e && e[0] == '1') ? 1 : 0; }
@@ -930,7 +950,8 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	{
 		// per key point: every orientation and descriptor sample reads 12 integral-image taps; angle + descriptor + sign written once
 		const int gridWv = t.widthLargeGrid * t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
-		const double perKp = (double)(t.oriWidth * t.oriWidth + gridWv * gridWv) * 12 * 4 + 8.0 * t.dof + 8 + 1;
+		const int nbv = P.nBands > 0 ? P.nBands : 1;
+		const double perKp = (double)(t.oriWidth * t.oriWidth + nbv * gridWv * gridWv) * 12 * 4 + 8.0 * t.dof * nbv + 8 + 1;
 		ProfScope ps(ctx, "k_describe", perKp * (double)total);
 		const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
 		const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);

@@ -372,3 +372,33 @@ int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, in
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
+
+
+// ---------------- band average of a planar image ----------------
+// ImplConvertPlanarToGray.average(Planar<GrayF32>, GrayF32)  I:core/image/impl/ImplConvertPlanarToGray.java:296-336:
+// one band: copy; three bands: sum = b0; sum += b1; sum += b2; sum / 3; otherwise sum = 0; sum += b_i ...; sum / numBands
+__global__ __launch_bounds__(256) void k_planar_average(const float* __restrict__ bands, long long bandStride, int numBands, long long n, float* __restrict__ out) {
+	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float r;
+	if (numBands == 1) {
+		r = bands[i];
+	} else if (numBands == 3) {
+		float sum = bands[i];
+		sum += bands[bandStride + i];
+		sum += bands[2 * bandStride + i];
+		r = sum / 3;
+	} else {
+		float sum = 0;
+		for (int b = 0; b < numBands; b++) sum += bands[b * bandStride + i];
+		r = sum / numBands;
+	}
+	out[i] = r;
+}
+int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out) {
+	if (n <= 0) return BHIP_OK;
+	ProfScope prof(ctx, "k_planar_average", 4.0 * n * (numBands + 1));
+	hipLaunchKernelGGL(k_planar_average, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, bands, bandStride, numBands, n, out);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}

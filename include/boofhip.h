@@ -108,6 +108,14 @@ int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* start
  * Asynchronous on the ctx stream apart from one small count read-back. */
 int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long imageStride, int stride, int width, int height, int batch);
 /* getNumberOfFeatures() */
+/* FactoryDetectDescribe.surfColorStable / surfColorFast (F:factory/feature/detdesc/FactoryDetectDescribe.java:154-176,246-268) on one
+ * Planar<GrayF32> frame given as numBands band pointers of one shape: SurfPlanar_to_DetectDescribePoint.detect
+ * (F:abst/feature/detdesc/SurfPlanar_to_DetectDescribePoint.java:62-77) = band average -> integral images of the average and of every band
+ * -> Fast-Hessian on the average -> DetectDescribeSurfPlanar.describe (F:alg/feature/detdesc/DetectDescribeSurfPlanar.java:110-124;
+ * orientation object radius = scale) -> DescribePointSurfPlanar.describe (F:alg/feature/describe/DescribePointSurfPlanar.java:100-114;
+ * bands concatenated, normalised once; Laplacian sign from the average).  Results through bhip_surf_count / _fetch / _dev_view with
+ * image = 0; bhip_surf_dof() then returns numBands * 64.  getRadius(i) of this wrapper is the scale itself (no factor 2). */
+int bhip_surf_detect_planar_f32(bhip_surf* s, const float* const* bands, int numBands, int startIndex, int stride, int width, int height);
 int bhip_surf_count(bhip_surf* s, int image, int* n);
 /* getLocation(i)/scale -> xy_scale[3n] ; getOrientation(i) -> angle[n] ; BrightFeature.white -> white[n] ;
  * getDescription(i).value -> desc[64n].  getRadius(i) = scale*2 (BoofDefaults.SURF_SCALE_TO_RADIUS).  Any pointer may be NULL. */

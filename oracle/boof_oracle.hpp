@@ -1137,6 +1137,67 @@ struct DetectDescribeSurf {
 		detector.detect(ii);
 		describeAll(detector.foundPoints, out);
 	}
+	// ---- colour SURF: SurfPlanar_to_DetectDescribePoint.detect (F:abst/feature/detdesc/SurfPlanar_to_DetectDescribePoint.java:62-77) +
+	// DetectDescribeSurfPlanar.detect/describe (F:alg/feature/detdesc/DetectDescribeSurfPlanar.java:91-124) +
+	// DescribePointSurfPlanar.describe (F:alg/feature/describe/DescribePointSurfPlanar.java:100-114).
+	// Differences from the grey wrapper, kept as in the reference: the orientation's object radius is p.scale (not 2*scale), the bands'
+	// descriptors are concatenated UN-normalised and normalised once as a whole, the Laplacian sign comes from the grey integral image.
+	std::vector<GrayF32> bandII;
+	GrayF32 grayAvg;
+	// ImplConvertPlanarToGray.average(Planar<GrayF32>) (I:core/image/impl/ImplConvertPlanarToGray.java:296-336)
+	static void averagePlanar(const std::vector<GrayF32>& bands, GrayF32& to) {
+		const int nb = (int)bands.size();
+		to.reshape(bands[0].width, bands[0].height);
+		for (int y = 0; y < to.height; y++)
+			for (int x = 0; x < to.width; x++) {
+				if (nb == 1) { to.set(x, y, bands[0].get(x, y)); continue; }
+				float sum;
+				if (nb == 3) { sum = bands[0].get(x, y); sum += bands[1].get(x, y); sum += bands[2].get(x, y); to.set(x, y, sum / 3); }
+				else { sum = 0; for (int b = 0; b < nb; b++) sum += bands[b].get(x, y); to.set(x, y, sum / nb); }
+			}
+	}
+	void detectPlanar(const std::vector<GrayF32>& bands, SurfResult& out) {
+		averagePlanar(bands, grayAvg);
+		ii.reshape(grayAvg.width, grayAvg.height);
+		integral_transform(grayAvg, ii);
+		bandII.resize(bands.size());
+		for (size_t b = 0; b < bands.size(); b++) { bandII[b].reshape(bands[b].width, bands[b].height); integral_transform(bands[b], bandII[b]); }
+		detector.threads = threads;
+		detector.detect(ii);
+		describeAllPlanar(detector.foundPoints, out);
+	}
+	void describeAllPlanar(const std::vector<ScalePoint>& pts, SurfResult& out) {
+		const int n = (int)pts.size(), D = dof(), nb = (int)bandII.size();
+		out.points = pts;
+		out.angles.assign(n, 0);
+		out.desc.assign((size_t)n * D * nb, 0);
+		out.white.assign(n, 0);
+#pragma omp parallel num_threads(threads) if (threads > 1)
+		{
+			OrientationSlidingWindow os = oriSliding;
+			OrientationAverage oa = oriAverage;
+			DescribePointSurfMod dm = describeMod;
+			DescribePointSurf df = describeFast;
+			os.setImage(ii); oa.setImage(ii);
+#pragma omp for schedule(dynamic, 16)
+			for (int i = 0; i < n; i++) {
+				const ScalePoint& p = pts[i];
+				double angle;
+				if (stable) { os.setObjectRadius(p.scale); angle = os.compute(p.x, p.y); }
+				else { oa.setObjectRadius(p.scale); angle = oa.compute(p.x, p.y); }
+				double* d = &out.desc[(size_t)i * D * nb];
+				DescribePointSurf& de = stable ? (DescribePointSurf&)dm : df;
+				for (int b = 0; b < nb; b++) {
+					de.setImage(bandII[b]);
+					de.describeTuple(p.x, p.y, angle, p.scale, d + (size_t)b * D);
+				}
+				normalizeL2(d, D * nb);
+				de.setImage(ii);
+				out.white[i] = de.computeLaplaceSign((int)(p.x + 0.5), (int)(p.y + 0.5), p.scale) ? 1 : 0;
+				out.angles[i] = angle;
+			}
+		}
+	}
 	void describeAll(const std::vector<ScalePoint>& pts, SurfResult& out) {
 		const int n = (int)pts.size(), D = dof();
 		out.points = pts;

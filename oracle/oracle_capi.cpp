@@ -214,6 +214,24 @@ int orc_surf_describe_points(void* h, const orc_image* img, const double* xys, i
 	s->dd->describeAll(pts, s->res);
 	return n;
 }
+// colour SURF on a planar image: bands[nb] share one shape; the descriptor has nb * dof values
+int orc_surf_detect_planar(void* h, const orc_image* bands, int nb, int threads) {
+	orc_surf* s = (orc_surf*)h;
+	s->dd->threads = threads;
+	std::vector<GrayF32> b(nb);
+	for (int i = 0; i < nb; i++) b[i] = view(&bands[i]);
+	s->dd->detectPlanar(b, s->res);
+	return (int)s->res.points.size();
+}
+// DescribePointSurfPlanar.describe for caller-supplied (x, y, scale) on the planar image of the last orc_surf_detect_planar
+int orc_surf_describe_points_planar(void* h, const double* xys, int n, int threads) {
+	orc_surf* s = (orc_surf*)h;
+	s->dd->threads = threads;
+	std::vector<ScalePoint> pts(n);
+	for (int i = 0; i < n; i++) pts[i] = {xys[3 * i], xys[3 * i + 1], xys[3 * i + 2]};
+	s->dd->describeAllPlanar(pts, s->res);
+	return n;
+}
 void orc_surf_fetch(void* h, double* xys, double* angle, uint8_t* white, double* desc) {
 	orc_surf* s = (orc_surf*)h;
 	size_t n = s->res.points.size();

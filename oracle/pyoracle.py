@@ -99,6 +99,8 @@ def lib():
             "orc_surf_destroy": (None, [C.c_void_p]),
             "orc_surf_detect": (C.c_int, [C.c_void_p, IM, C.c_int]),
             "orc_surf_describe_points": (C.c_int, [C.c_void_p, IM, P(C.c_double), C.c_int, C.c_int]),
+            "orc_surf_detect_planar": (C.c_int, [C.c_void_p, P(_Image), C.c_int, C.c_int]),
+            "orc_surf_describe_points_planar": (C.c_int, [C.c_void_p, P(C.c_double), C.c_int, C.c_int]),
             "orc_surf_fetch": (None, [C.c_void_p, P(C.c_double), P(C.c_double), P(C.c_uint8), P(C.c_double)]),
             "orc_surf_integral": (None, [C.c_void_p, P(C.c_float)]),
             "orc_associate_l2": (None, [P(C.c_double), C.c_int, P(C.c_double), C.c_int, C.c_int, C.c_double, C.c_int, P(C.c_int), P(C.c_double), C.c_int]),
@@ -276,17 +278,31 @@ class Surf:
 
     def detect(self, img, threads=1):
         self.n = lib().orc_surf_detect(self._h, img.c(), threads)
+        self._bands = 1
         self._shape = (img.width, img.height)
+        return self.n
+
+    def detect_planar(self, bands, threads=1):
+        """FactoryDetectDescribe.surfColorStable / surfColorFast on a Planar<GrayF32> given as a list of Gray bands."""
+        arr = (_Image * len(bands))(*[_Image(_fp(b.buf), b.startIndex, b.stride, b.width, b.height) for b in bands])
+        self.n = lib().orc_surf_detect_planar(self._h, arr, len(bands), threads)
+        self._bands = len(bands)
+        return self.n
+
+    def describe_points_planar(self, xys, threads=1):
+        xys = np.ascontiguousarray(xys, dtype=np.float64)
+        self.n = lib().orc_surf_describe_points_planar(self._h, _fp(xys, C.c_double), len(xys), threads)
         return self.n
 
     def describe_points(self, xys, img=None, threads=1):
         xys = np.ascontiguousarray(xys, dtype=np.float64)
         self.n = lib().orc_surf_describe_points(self._h, img.c() if img is not None else None, _fp(xys, C.c_double), len(xys), threads)
+        self._bands = 1
         return self.n
 
     def fetch(self):
         n = self.n
-        xys = np.zeros((n, 3)); ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); desc = np.zeros((n, self.dof))
+        xys = np.zeros((n, 3)); ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); desc = np.zeros((n, self.dof * getattr(self, "_bands", 1)))
         lib().orc_surf_fetch(self._h, _fp(xys, C.c_double), _fp(ang, C.c_double), _fp(white, C.c_uint8), _fp(desc, C.c_double))
         return xys, ang, white, desc
 

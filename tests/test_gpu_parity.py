@@ -654,6 +654,36 @@ def test_detector_plans_agree(api, orc, tmp_path):
         assert np.array_equal(np.load(out), base), env
 
 
+@pytest.mark.parametrize("stable", [True, False])
+def test_surf_color_planar_parity(api, orc, stable):
+    """FactoryDetectDescribe.surfColorStable / surfColorFast on Planar<GrayF32>: key points from the band average bit-exact,
+    192-value descriptors inside the 1e-5 bar, Laplacian sign from the average, getRadius == scale; sub-image bands; band-count check."""
+    rand = orc.JavaRandom(234)
+    for (w, h, nb) in [(150, 120, 3), (200, 160, 3), (120, 100, 2), (90, 80, 4)]:
+        bands = [rand.fillUniform(orc.Gray(w, h), 0, 200) for _ in range(nb)]
+        ref = orc.Surf(stable)
+        n = ref.detect_planar(bands, threads=4)
+        pts, ang, white, desc = ref.fetch()
+        fac = api.FactoryDetectDescribe.surfColorStable if stable else api.FactoryDetectDescribe.surfColorFast
+        dd = fac(None, None, None, api.PlanarType(nb))
+        dd.detect(api.Planar.wrap([G(api, b) for b in bands]))
+        got = dd._results()
+        assert n > 10 and dd.getNumberOfFeatures() == n and dd.createDescription().size() == 64 * nb
+        assert np.array_equal(got[0], pts) and np.array_equal(got[2], white)
+        assert np.max(np.abs(np.angle(np.exp(1j * (got[1] - ang))))) < 1e-9
+        derr = np.max(np.abs(got[3] - desc), axis=1)
+        assert (derr <= DESC_TOL).mean() >= 0.999, (w, h, nb, derr.max())
+        assert dd.getRadius(0) == pts[0, 2] and dd.getOrientation(0) == got[1][0]
+        # sub-image bands (shared startIndex / stride)
+        dd.detect(api.Planar.wrap([G(api, b.sub_image_of()) for b in bands]))
+        sub = dd._results()
+        assert all(np.array_equal(a, b) for a, b in zip(got, sub))
+    with pytest.raises(api.IllegalArgumentException):
+        dd.detect(api.Planar.wrap([G(api, bands[0])]))
+    with pytest.raises(api.IllegalArgumentException):
+        api.FactoryDetectDescribe.surfColorStable(None, None, None, api.GrayF32)
+
+
 def test_associate_surf_basic(api, orc):
     """AssociateSurfBasic / WrapAssociateSurfBasic (TestAssociateSurfBasic.java literals + detected SURF features of two noise images)."""
     def feats(desc, white):

@@ -570,3 +570,30 @@ def test_associate_surf_basic_literals(orc):
     # handleEmptyLists :153-: empty source or destination gives no matches
     assert orc.associate_surf_basic(_surf_desc([]), [], _surf_desc([10]), [True]) == ([], [])
     assert orc.associate_surf_basic(_surf_desc([10]), [True], _surf_desc([]), []) == ([], [])
+
+
+# ---------------------------------------------------------------------------------------------------
+# Colour SURF   FT:alg/feature/describe/TestDescribePointSurfPlanar.java:48-89
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("stable", [True, False])
+def test_surf_planar_compare_to_single_band(orc, stable):
+    rand = orc.JavaRandom(234)
+    bands = [rand.fillUniform(orc.Gray(150, 120), 0, 200) for _ in range(3)]
+    s = orc.Surf(stable)
+    n = s.detect_planar(bands)
+    assert n > 20
+    pts, ang, white, desc = s.fetch()
+    assert desc.shape == (n, 192) and np.allclose(np.linalg.norm(desc, axis=1), 1, atol=1e-12)
+    # detector ran on the band average (ImplConvertPlanarToGray.average: (b0 + b1 + b2) / 3 in float)
+    avg = ((bands[0].array() + bands[1].array()) + bands[2].array()) / np.float32(3)
+    g = orc.Surf(stable)
+    g.detect(orc.Gray.from_array(avg))
+    gp, gang, gwhite, _ = g.fetch()
+    assert np.array_equal(gp, pts) and np.array_equal(gwhite, white)
+    # every band's block, renormalised on its own, equals the single-band descriptor of that band at the same (x, y, angle, scale)
+    for b in range(3):
+        bii = orc.integral(bands[b])
+        for i in range(0, n, max(1, n // 25)):
+            d1, _ = orc.describe(bii, pts[i, 0], pts[i, 1], ang[i], pts[i, 2], stable=stable)
+            blk = desc[i, 64 * b:64 * (b + 1)]
+            assert np.abs(blk / np.linalg.norm(blk) - d1).max() < 1e-8
