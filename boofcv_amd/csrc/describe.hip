@@ -83,10 +83,12 @@ __device__ __forceinline__ void gradSample(const float* __restrict__ d, const Gr
 	const int r = G.r;
 	const bool inb = x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < G.W && y + r < G.H;
 	const int xs = inb ? x : G.safe, ys = inb ? y : G.safe;
-	const long long s1 = (long long)(ys - r - 1) * G.stride + (xs - r - 1);
-	const long long s2 = s1 + (long long)r * G.stride;
-	const long long s3 = s2 + G.stride;
-	const long long s4 = s3 + (long long)r * G.stride;
+	// 32-bit element offsets from the (wave-uniform) image base: one integral image is far below 2^31 floats (W, H < 32768 is enforced
+	// by the detector, and the host rejects larger images for describe), and a uniform base + 32-bit lane offset is the cheap address form
+	const int s1 = (ys - r - 1) * G.stride + (xs - r - 1);
+	const int s2 = s1 + r * G.stride;
+	const int s3 = s2 + G.stride;
+	const int s4 = s3 + r * G.stride;
 	const int w = G.w;
 	const float p0 = d[s1], p1 = d[s1 + r], p2 = d[s1 + r + 1], p3 = d[s1 + w];
 	const float p11 = d[s2], p4 = d[s2 + w];
@@ -910,6 +912,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	if (P.ldsPerWave * 4 > 160 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation/descriptor sample grid too large for LDS");
 	const long long blocks = ((((total + 3) / 4) + 7) / 8) * 8;   // whole rounds over the 8 XCDs
 	if (blocks > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_INVALID, "too many key points");
+	if ((long long)ii.stride * ii.height > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "integral image too large for 32-bit tap offsets");
 	const char* stampPath = getenv("BHIP_DESCRIBE_STAMPS");
 	if (stampPath && total > 1000) {
 		// diagnostic build: phase shares of the describe kernel (never a quoted run time)
