@@ -822,6 +822,88 @@ class FactoryFeatureExtractor:
         return NonMaxSuppression(config, ctx)
 
 
+class GradientCornerIntensity:
+    """FactoryIntensityPointAlg.shiTomasi / harris (unweighted, GrayF32 derivatives): ImplSsdCorner_F32 with ShiTomasiCorner_F32 /
+    HarrisCorner_F32 (F:alg/feature/detect/intensity/impl/ImplSsdCorner_F32.java:62-196).  Single-threaded summation order."""
+
+    def __init__(self, kind, windowRadius, kappa=0.0, ctx=None):
+        self.kind, self.radius, self.kappa = kind, int(windowRadius), float(kappa)
+        self.ctx = _ctx(ctx)
+
+    def getRadius(self):
+        return self.radius
+
+    def getIgnoreBorder(self):
+        return self.radius
+
+    def process(self, derivX, derivY, intensity):
+        if derivX.width != derivY.width or derivX.height != derivY.height:
+            raise IllegalArgumentException("Image shapes do not match")   # InputSanityCheck.checkSameShape
+        if (derivX.startIndex, derivX.stride) != (derivY.startIndex, derivY.stride):
+            raise IllegalArgumentException("derivX and derivY must share startIndex and stride")
+        intensity.reshape(derivX.width, derivX.height)
+        _check(self.ctx, _lib.load().bhip_corner_intensity_f32(self.ctx._h, self.kind, self.radius, self.kappa, derivX._p(), derivY._p(), derivX.startIndex,
+                                                               derivX.stride, derivX.width, derivX.height, intensity._p(), intensity.startIndex,
+                                                               intensity.stride))
+
+
+class FactoryIntensityPointAlg:
+    @staticmethod
+    def shiTomasi(windowRadius, weighted=False, derivType=None, ctx=None):
+        """F:factory/feature/detect/intensity/FactoryIntensityPointAlg.java:132-160"""
+        if weighted or (derivType is not None and derivType is not GrayF32):
+            raise RuntimeError("only the unweighted GrayF32 corner intensity is implemented on the GPU (use the Java path)")
+        return GradientCornerIntensity(0, windowRadius, 0.0, ctx)
+
+    @staticmethod
+    def harris(windowRadius, kappa, weighted=False, derivType=None, ctx=None):
+        """F:factory/feature/detect/intensity/FactoryIntensityPointAlg.java:91-118"""
+        if weighted or (derivType is not None and derivType is not GrayF32):
+            raise RuntimeError("only the unweighted GrayF32 corner intensity is implemented on the GPU (use the Java path)")
+        return GradientCornerIntensity(1, windowRadius, kappa, ctx)
+
+
+class GeneralFeatureDetector:
+    """F:alg/feature/detect/interest/GeneralFeatureDetector.java:67-160 for a gradient corner intensity and a maxima extractor:
+    intensity.process -> extractor.process.  maxFeatures > 0 selects with ddogleg's QuickSelect, whose order is not pinned by the
+    reference tree -> RuntimeError (use the Java path)."""
+
+    def __init__(self, intensity, extractor):
+        self.intensity, self.extractor = intensity, extractor
+        if intensity.getIgnoreBorder() > extractor.getIgnoreBorder():
+            extractor.setIgnoreBorder(intensity.getIgnoreBorder())
+        self.maxFeatures = 0
+        self.intensityImage = GrayF32(1, 1)
+        self.foundMaximum = []
+
+    def setMaxFeatures(self, n):
+        if n > 0:
+            raise RuntimeError("maxFeatures > 0 (QuickSelect order unpinned): use the Java path")
+        self.maxFeatures = n
+
+    def getRequiresGradient(self):
+        return True
+
+    def getRequiresHessian(self):
+        return False
+
+    def setThreshold(self, threshold):
+        self.extractor.setThresholdMaximum(threshold)
+
+    def getThreshold(self):
+        return self.extractor.getThresholdMaximum()
+
+    def process(self, image, derivX, derivY, derivXX=None, derivYY=None, derivXY=None):
+        self.intensity.process(derivX, derivY, self.intensityImage)
+        self.foundMaximum = self.extractor.process(self.intensityImage)
+
+    def getIntensity(self):
+        return self.intensityImage
+
+    def getMaximums(self):
+        return self.foundMaximum
+
+
 class FastHessianFeatureDetector:
     """FactoryInterestPointAlgs.fastHessian(config).detect(integral) (F:alg/feature/detect/interest/FastHessianFeatureDetector.java:156-188)"""
 

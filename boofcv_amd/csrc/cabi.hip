@@ -21,6 +21,8 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
 						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch);
 int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out);
+int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dx, const float* dy, int dStride, int width, int height,
+								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride);
 int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out);
@@ -1075,6 +1077,26 @@ int bhip_three_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, in
 				   int border) {
 	CHECK_CTX(ctx);
 	return gradHost(ctx, 1, in, inStart, inStride, width, height, dx, dy, outStart, outStride, border);
+}
+
+// FactoryIntensityPointAlg.shiTomasi / harris (unweighted, GrayF32) -> GradientCornerIntensity.process(derivX, derivY, intensity)
+int bhip_corner_intensity_f32(bhip_ctx* ctx, int kind, int radius, float kappa, const float* derivX, const float* derivY, int dStart, int dStride, int width,
+							  int height, float* intensity, int iStart, int iStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, derivX, dStride, width, height);
+	CHECK_IMG(ctx, derivY, dStride, width, height);
+	CHECK_IMG(ctx, intensity, iStride, width, height);
+	CtxScratch* sc = scratchOf(ctx);
+	const size_t px = (size_t)width * height;
+	BHIP_TRY(uploadImage(ctx, sc->a, derivX, dStart, dStride, width, height));
+	BHIP_TRY(uploadImage(ctx, sc->b, derivY, dStart, dStride, width, height));
+	BHIP_TRY(sc->c.reserve(ctx, px * 4 * 3));
+	BHIP_TRY(sc->d.reserve(ctx, px * 4));
+	BHIP_HIP(ctx, hipMemsetAsync(sc->d.p, 0, px * 4, ctx->stream));   // ImageMiscOps.fillBorder(intensity, 0, radius); the interior is overwritten
+	float* h = sc->c.as<float>();
+	BHIP_TRY(bhip_launch_corner_intensity(ctx, kind, radius, kappa, sc->a.as<float>(), sc->b.as<float>(), width, width, height, h, h + px, h + 2 * px,
+										  sc->d.as<float>(), width));
+	return downloadImage(ctx, sc->d.p, intensity, iStart, iStride, width, height);
 }
 
 int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int width, int height, int radius, int numPoints,

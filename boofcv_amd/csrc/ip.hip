@@ -402,3 +402,91 @@ int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long band
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
+
+
+// ---------------- gradient corner intensity (Shi-Tomasi / Harris on box-window sums of the gradient products) ----------------
+// GradientCornerIntensity.process = ImplSsdCornerBox.process   F:alg/feature/detect/intensity/impl/ImplSsdCornerBox.java:36-51
+//   horizontal() / vertical()                                  F:alg/feature/detect/intensity/impl/ImplSsdCorner_F32.java:62-127, 133-196
+//   scores                                                     F:.../impl/ShiTomasiCorner_F32.java:33-42, HarrisCorner_F32.java:45-50
+// The reference's window sums are running float sums (subtract the sample leaving the window, add the one entering), so every value
+// depends on the history of its whole row (horizontal pass) or column (vertical pass).  The chains are kept exactly: one thread walks
+// one row, then one thread walks one column; parallelism is across rows / columns (and images).  Bound: the horizontal pass is a
+// latency chain over W per row (each lane streams its own row through L1); the vertical pass is coalesced and HBM bound (12P read, 4P write).
+struct CornerParams {
+	const float* dx; const float* dy;
+	int dStride, width, height, radius;
+	float* hXX; float* hXY; float* hYY;   // dense width x height planes
+	float* intensity; int iStride;
+	int kind; float kappa;
+};
+
+__global__ __launch_bounds__(64) void k_corner_rows(CornerParams P) {
+	const int row = blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= P.height) return;
+	const int W = P.width, r = P.radius, ww = 2 * r + 1;
+	const float* __restrict__ X = P.dx + (long long)row * P.dStride;
+	const float* __restrict__ Y = P.dy + (long long)row * P.dStride;
+	float* oXX = P.hXX + (long long)row * W; float* oXY = P.hXY + (long long)row * W; float* oYY = P.hYY + (long long)row * W;
+	float tXX = 0, tXY = 0, tYY = 0;
+	for (int i = 0; i < ww; i++) {
+		const float dx = X[i], dy = Y[i];
+		tXX += dx * dx; tXY += dx * dy; tYY += dy * dy;
+	}
+	oXX[r] = tXX; oXY[r] = tXY; oYY[r] = tYY;
+	for (int i = ww; i < W; i++) {
+		float dx = X[i - ww], dy = Y[i - ww];
+		tXX -= dx * dx; tXY -= dx * dy; tYY -= dy * dy;
+		dx = X[i]; dy = Y[i];
+		tXX += dx * dx; tXY += dx * dy; tYY += dy * dy;
+		oXX[i - r] = tXX; oXY[i - r] = tXY; oYY[i - r] = tYY;
+	}
+}
+
+__device__ __forceinline__ float cornerScore(int kind, float kappa, float xx, float xy, float yy) {
+	if (kind == 0) {
+		const float left = (xx + yy) * 0.5f;
+		const float b = (xx - yy) * 0.5f;
+		const float right = sqrtf(b * b + xy * xy);   // (float)Math.sqrt((double)f) == correctly rounded float sqrt
+		return left - right;
+	}
+	const float trace = xx + yy;
+	return (xx * yy - xy * xy) - kappa * trace * trace;
+}
+
+__global__ __launch_bounds__(256) void k_corner_cols(CornerParams P) {
+	const int W = P.width, H = P.height, r = P.radius, kw = 2 * r + 1;
+	const int x = r + blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= W - r) return;
+	const float* __restrict__ hXX = P.hXX; const float* __restrict__ hXY = P.hXY; const float* __restrict__ hYY = P.hYY;
+	float tXX = 0, tXY = 0, tYY = 0;
+	for (int k = 0; k < kw; k++) {
+		const long long s = (long long)k * W + x;
+		tXX += hXX[s]; tXY += hXY[s]; tYY += hYY[s];
+	}
+	P.intensity[(long long)r * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
+	for (int y = r + 1; y < H - r; y++) {
+		const long long in = (long long)(y + r) * W + x, out = in - (long long)kw * W;
+		tXX = tXX - hXX[out]; tXX += hXX[in];
+		tXY = tXY - hXY[out]; tXY += hXY[in];
+		tYY = tYY - hYY[out]; tYY += hYY[in];
+		P.intensity[(long long)y * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
+	}
+}
+
+// intensity (dense, iStride == width here) must be zero along its border of `radius` pixels: the caller clears the whole image first
+int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dx, const float* dy, int dStride, int width, int height,
+								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride) {
+	if (kind != 0 && kind != 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "corner score not supported");
+	if (radius < 0 || 2 * radius + 1 > width || 2 * radius + 1 > height) return bhip_fail(ctx, BHIP_ERR_INVALID, "window larger than the image");
+	CornerParams P{dx, dy, dStride, width, height, radius, hXX, hXY, hYY, intensity, iStride, kind, kappa};
+	{
+		ProfScope prof(ctx, "k_corner_rows", 4.0 * width * height * 5);
+		hipLaunchKernelGGL(k_corner_rows, dim3((height + 63) / 64), dim3(64), 0, ctx->stream, P);
+	}
+	{
+		ProfScope prof(ctx, "k_corner_cols", 4.0 * width * height * 4);
+		hipLaunchKernelGGL(k_corner_cols, dim3((width - 2 * radius + 255) / 256), dim3(256), 0, ctx->stream, P);
+	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}

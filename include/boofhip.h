@@ -229,6 +229,15 @@ int bhip_pyramid_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, const 
 					 int inStride, int width, int height, float* out);
 int bhip_pyramid_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, const int* scales, int numLayers, const float* dev_in,
 						 long long inImageStride, int inStride, int width, int height, int batch, float* dev_out);
+/* FactoryIntensityPointAlg.shiTomasi(radius, false, GrayF32) / harris(radius, kappa, false, GrayF32)
+ * (F:factory/feature/detect/intensity/FactoryIntensityPointAlg.java:91-160) -> GradientCornerIntensity.process(derivX, derivY, intensity)
+ * = ImplSsdCorner_F32 (F:alg/feature/detect/intensity/impl/ImplSsdCorner_F32.java:62-196, ImplSsdCornerBox.java:36-51) with
+ * ShiTomasiCorner_F32 (kind 0) or HarrisCorner_F32 (kind 1): box-window running sums of dx*dx, dx*dy, dy*dy in the reference's
+ * single-threaded order (bit-exact), intensity 0 inside the border of `radius` pixels.  derivX / derivY share startIndex and stride.
+ * Together with bhip_sobel_f32 and bhip_nonmax_block_f32 this is GeneralFeatureDetector.process for maxFeatures <= 0
+ * (F:alg/feature/detect/interest/GeneralFeatureDetector.java:118-160). */
+int bhip_corner_intensity_f32(bhip_ctx* ctx, int kind, int radius, float kappa, const float* derivX, const float* derivY, int dStart, int dStride,
+							  int width, int height, float* intensity, int iStart, int iStride);
 /* DescribePointBrief.process for n points on one image (F:alg/feature/describe/DescribePointBrief.java:73-89;
  * F:alg/feature/describe/impl/ImplDescribeBinaryCompare_F32.java:47-101).  The definition (samplePoints[numPoints][2], compare[numPoints][2])
  * is supplied by the caller: FactoryBriefDefinition.gaussian2 depends on java.util.Random + StrictMath and is generated on the Java side. */

@@ -549,6 +549,85 @@ struct PyramidDiscreteSampleBlur {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Gradient corner intensity: ImplSsdCorner_F32 (box window, running sums) with the Shi-Tomasi / Harris scores
+//   F:alg/feature/detect/intensity/impl/ImplSsdCornerBox.java:36-51 (border of the intensity image filled with 0)
+//   F:alg/feature/detect/intensity/impl/ImplSsdCorner_F32.java:62-127 horizontal(), :133-196 vertical()
+//   F:alg/feature/detect/intensity/impl/ShiTomasiCorner_F32.java:33-42, HarrisCorner_F32.java:45-50
+// The window sums are RUNNING sums in float (subtract the element leaving, add the one entering), so every value depends on the whole
+// history of its row / column: the single-threaded order is restated literally.
+// ------------------------------------------------------------------------------------------------
+inline float cornerShiTomasi(float totalXX, float totalXY, float totalYY) {
+	float left = (totalXX + totalYY) * 0.5f;
+	float b = (totalXX - totalYY) * 0.5f;
+	float right = (float)std::sqrt((double)(b * b + totalXY * totalXY));
+	return left - right;
+}
+inline float cornerHarris(float kappa, float totalXX, float totalXY, float totalYY) {
+	float trace = totalXX + totalYY;
+	return (totalXX * totalYY - totalXY * totalXY) - kappa * trace * trace;
+}
+// kind: 0 Shi-Tomasi, 1 Harris(kappa), 2 the reference test's MockSum (xx + xy + yy)
+inline void ssdCornerF32(const GrayF32& derivX, const GrayF32& derivY, int radius, int kind, float kappa, GrayF32& intensity) {
+	const int imgWidth = derivX.width, imgHeight = derivX.height;
+	if (derivY.width != imgWidth || derivY.height != imgHeight) throw std::invalid_argument("shapes do not match");
+	intensity.reshape(imgWidth, imgHeight);
+	// ImageMiscOps.fillBorder(intensity, 0, radius); the interior is overwritten below (only where 2*radius < size)
+	for (int y = 0; y < imgHeight; y++)
+		for (int x = 0; x < imgWidth; x++)
+			if (x < radius || x >= imgWidth - radius || y < radius || y >= imgHeight - radius) intensity.set(x, y, 0);
+	auto score = [&](float xx, float xy, float yy) { return kind == 0 ? cornerShiTomasi(xx, xy, yy) : kind == 1 ? cornerHarris(kappa, xx, xy, yy) : xx + xy + yy; };
+	std::vector<float> hXX((size_t)imgWidth * imgHeight, 0.f), hXY(hXX), hYY(hXX);
+	const int windowWidth = radius * 2 + 1, radp1 = radius + 1;
+	if (windowWidth > imgWidth || windowWidth > imgHeight) throw std::invalid_argument("window larger than the image");
+	for (int row = 0; row < imgHeight; row++) {
+		int pix = row * imgWidth;
+		int end = pix + windowWidth;
+		float totalXX = 0, totalXY = 0, totalYY = 0;
+		int indexX = derivX.startIndex + row * derivX.stride;
+		int indexY = derivY.startIndex + row * derivY.stride;
+		for (; pix < end; pix++) {
+			float dx = derivX.data[indexX++], dy = derivY.data[indexY++];
+			totalXX += dx * dx; totalXY += dx * dy; totalYY += dy * dy;
+		}
+		hXX[pix - radp1] = totalXX; hXY[pix - radp1] = totalXY; hYY[pix - radp1] = totalYY;
+		end = row * imgWidth + imgWidth;
+		for (; pix < end; pix++, indexX++, indexY++) {
+			float dx = derivX.data[indexX - windowWidth], dy = derivY.data[indexY - windowWidth];
+			totalXX -= dx * dx; totalXY -= dx * dy; totalYY -= dy * dy;
+			dx = derivX.data[indexX]; dy = derivY.data[indexY];
+			totalXX += dx * dx; totalXY += dx * dy; totalYY += dy * dy;
+			hXX[pix - radius] = totalXX; hXY[pix - radius] = totalXY; hYY[pix - radius] = totalYY;
+		}
+	}
+	const int kernelWidth = windowWidth, startX = radius, endX = imgWidth - radius, backStep = kernelWidth * imgWidth;
+	const int y0 = radius, y1 = imgHeight - radius;
+	std::vector<float> tempXX(imgWidth), tempXY(imgWidth), tempYY(imgWidth);
+	float* inten = intensity.data + intensity.startIndex;   // reshape() above made it dense
+	for (int x = startX; x < endX; x++) {
+		int srcIndex = x + (y0 - radius) * imgWidth;
+		int destIndex = imgWidth * y0 + x;
+		float totalXX = 0, totalXY = 0, totalYY = 0;
+		int indexEnd = srcIndex + imgWidth * kernelWidth;
+		for (; srcIndex < indexEnd; srcIndex += imgWidth) { totalXX += hXX[srcIndex]; totalXY += hXY[srcIndex]; totalYY += hYY[srcIndex]; }
+		tempXX[x] = totalXX; tempXY[x] = totalXY; tempYY[x] = totalYY;
+		inten[destIndex] = score(totalXX, totalXY, totalYY);
+	}
+	for (int y = y0 + 1; y < y1; y++) {
+		int srcIndex = (y + radius) * imgWidth + startX;
+		int destIndex = y * imgWidth + startX;
+		for (int x = startX; x < endX; x++, srcIndex++, destIndex++) {
+			float totalXX = tempXX[x] - hXX[srcIndex - backStep];
+			tempXX[x] = totalXX += hXX[srcIndex];
+			float totalXY = tempXY[x] - hXY[srcIndex - backStep];
+			tempXY[x] = totalXY += hXY[srcIndex];
+			float totalYY = tempYY[x] - hYY[srcIndex - backStep];
+			tempYY[x] = totalYY += hYY[srcIndex];
+			inten[destIndex] = score(totalXX, totalXY, totalYY);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // BRIEF   F:alg/feature/describe/brief/FactoryBriefDefinition.java, DescribePointBinaryCompare.java,
 //         impl/ImplDescribeBinaryCompare_F32.java
 // ------------------------------------------------------------------------------------------------

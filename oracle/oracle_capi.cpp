@@ -340,6 +340,15 @@ long orc_pyramid(const float* kernel, int kw, double sigma, const int* scales, i
 		return off;
 	} catch (const DownConvError&) { return -1; }
 }
+// GradientCornerIntensity.process; out must be a dense width x height image.  Returns -1 where the reference throws.
+int orc_ssd_corner(const orc_image* dx, const orc_image* dy, int radius, int kind, float kappa, float* out) {
+	try {
+		GrayF32 inten(dx->width, dx->height);
+		ssdCornerF32(view(dx), view(dy), radius, kind, kappa, inten);
+		std::memcpy(out, inten.data, sizeof(float) * (size_t)dx->width * dx->height);
+	} catch (const std::exception&) { return -1; }
+	return 0;
+}
 void orc_subsample(const orc_image* in, const orc_image* out, int skip) { GrayF32 o = view(out); pyramidSubsample(view(in), o, skip); }
 
 }  // extern "C"

@@ -119,6 +119,7 @@ def lib():
             "orc_sobel": (None, [IM, IM, IM, C.c_int, C.c_int]),
             "orc_three": (None, [IM, IM, IM, C.c_int, C.c_int]),
             "orc_subsample": (None, [IM, IM, C.c_int]),
+            "orc_ssd_corner": (C.c_int, [IM, IM, C.c_int, C.c_int, C.c_float, P(C.c_float)]),
             "orc_conv_down_norm": (C.c_int, [C.c_int, P(C.c_float), C.c_int, IM, IM, C.c_int]),
             "orc_down_max_side": (C.c_int, [C.c_int, C.c_int, C.c_int]),
             "orc_down_offset": (C.c_int, [C.c_int, C.c_int]),
@@ -385,6 +386,15 @@ def conv(kind, kernel, offset, src, threads=1):
     k, kp = _kernel(kernel)
     out = Gray(src.width, src.height)
     getattr(lib(), "orc_conv_" + kind)(kp, len(k), offset, src.c(), out.c(), threads)
+    return out
+
+
+def corner_intensity(derivX, derivY, radius, kind="shitomasi", kappa=0.04):
+    """FactoryIntensityPointAlg.shiTomasi / harris (unweighted, GrayF32) .process(derivX, derivY, intensity) -> (H, W) float32."""
+    k = {"shitomasi": 0, "harris": 1, "mocksum": 2}[kind]
+    out = np.zeros((derivX.height, derivX.width), dtype=np.float32)
+    if lib().orc_ssd_corner(derivX.c(), derivY.c(), radius, k, np.float32(kappa), _fp(out)) != 0:
+        raise ValueError("corner intensity rejected")
     return out
 
 

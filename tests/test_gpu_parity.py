@@ -684,6 +684,37 @@ def test_surf_color_planar_parity(api, orc, stable):
         api.FactoryDetectDescribe.surfColorStable(None, None, None, api.GrayF32)
 
 
+@pytest.mark.parametrize("w,h", [(40, 50), (320, 240), (1920, 1080), (7, 9)])
+def test_corner_intensity_and_general_detector(api, orc, w, h):
+    """Shi-Tomasi / Harris gradient corner intensity (running box sums in the reference's order: bit-exact), then
+    GeneralFeatureDetector = intensity -> strict non-maximum suppression."""
+    img = orc.noise_image(w, h, 234)
+    dxo, dyo = orc.gradient("sobel", img, border_zero=True)
+    dx, dy = api.GrayF32(w, h), api.GrayF32(w, h)
+    api.GradientSobel.process(G(api, img), dx, dy, 0)
+    for radius in (1, 2, 3):
+        if 2 * radius + 1 > min(w, h):
+            continue
+        for alg, kind, kappa in [(api.FactoryIntensityPointAlg.shiTomasi(radius, False, api.GrayF32), "shitomasi", 0.0),
+                                 (api.FactoryIntensityPointAlg.harris(radius, 0.04, False, api.GrayF32), "harris", 0.04)]:
+            inten = api.GrayF32(1, 1)
+            alg.process(dx, dy, inten)
+            exp = orc.corner_intensity(dxo, dyo, radius, kind, kappa)
+            assert np.array_equal(bits(inten.array()), bits(exp)), (radius, kind)
+            assert alg.getRadius() == radius and alg.getIgnoreBorder() == radius
+    if min(w, h) >= 40:
+        cfg = api.ConfigExtract(radius=2, threshold=1.0, ignoreBorder=0)
+        det = api.GeneralFeatureDetector(api.FactoryIntensityPointAlg.shiTomasi(2, False, api.GrayF32), api.FactoryFeatureExtractor.nonmax(cfg))
+        det.process(G(api, img), dx, dy)
+        got = [(p.x, p.y) for p in det.getMaximums()]
+        exp = orc.nonmax(orc.Gray.from_array(orc.corner_intensity(dxo, dyo, 2, "shitomasi")), 2, 1.0, 2)
+        assert len(got) > 5 and got == [(int(x), int(y)) for x, y in exp]
+        with pytest.raises(RuntimeError):
+            det.setMaxFeatures(10)
+    with pytest.raises(api.IllegalArgumentException):
+        api.FactoryIntensityPointAlg.shiTomasi(5, False, api.GrayF32).process(api.GrayF32(6, 6), api.GrayF32(6, 6), api.GrayF32(1, 1))
+
+
 def test_associate_surf_basic(api, orc):
     """AssociateSurfBasic / WrapAssociateSurfBasic (TestAssociateSurfBasic.java literals + detected SURF features of two noise images)."""
     def feats(desc, white):

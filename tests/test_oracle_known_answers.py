@@ -597,3 +597,31 @@ def test_surf_planar_compare_to_single_band(orc, stable):
             d1, _ = orc.describe(bii, pts[i, 0], pts[i, 1], ang[i], pts[i, 2], stable=stable)
             blk = desc[i, 64 * b:64 * (b + 1)]
             assert np.abs(blk / np.linalg.norm(blk) - d1).max() < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------
+# Gradient corner intensity
+# ---------------------------------------------------------------------------------------------------
+def test_ssd_corner_compare_to_manual(orc):  # FT:alg/feature/detect/intensity/impl/TestImplSsdCorner_F32.java:55-86
+    width, height, radius = 40, 50, 4
+    inp = orc.JavaRandom(234).fillUniform(orc.Gray(width, height), 0, 100)
+    dx, dy = orc.gradient("sobel", inp, border_zero=True)   # the test uses an extended border; any gradient exercises the sums
+    got = orc.corner_intensity(dx, dy, radius, "mocksum")
+    x, y = dx.array().astype(np.float64), dy.array().astype(np.float64)
+    prod = x * x + x * y + y * y
+    for yy in range(radius, height - radius):
+        for xx in range(radius, width - radius):
+            assert abs(prod[yy - radius:yy + radius + 1, xx - radius:xx + radius + 1].sum() - got[yy, xx]) < 1   # the reference test's absolute tolerance
+    assert np.all(got[:radius] == 0) and np.all(got[:, :radius] == 0) and np.all(got[-radius:] == 0) and np.all(got[:, -radius:] == 0)
+
+
+def test_corner_scores_known_values(orc):  # TestShiTomasiCorner_F32 / TestHarrisCorner_F32: closed forms on a constant-gradient patch
+    w = h = 12
+    dx = orc.Gray.from_array(np.full((h, w), 2.0, np.float32)); dy = orc.Gray.from_array(np.full((h, w), 0.0, np.float32))
+    st = orc.corner_intensity(dx, dy, 1, "shitomasi"); ha = orc.corner_intensity(dx, dy, 1, "harris", 0.04)
+    # A = [[36, 0], [0, 0]]: smallest eigenvalue 0; Harris = det - k trace^2 = -0.04 * 36^2
+    assert st[5, 5] == 0 and abs(ha[5, 5] + 0.04 * 36 * 36) < 1e-3
+    dy = orc.Gray.from_array(np.full((h, w), 3.0, np.float32))
+    st = orc.corner_intensity(dx, dy, 1, "shitomasi")
+    # A = 9 * [[4, 6], [6, 9]]: eigenvalues 0 and 117
+    assert abs(st[5, 5]) < 1e-3
