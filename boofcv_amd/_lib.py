@@ -88,6 +88,9 @@ SIGNATURES = {
     "bhip_pyramid_layout": (_i, [_i, _i, _ip, _i, _ip, _llp, _llp]),
     "bhip_pyramid_f32": (_i, [_vp, _fp, _i, _ip, _i, _fp, _i, _i, _i, _i, _fp]),
     "bhip_pyramid_dev_f32": (_i, [_vp, _fp, _i, _ip, _i, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "bhip_conv2d_f32": (_i, [_vp, _fp, _i, _i, _fp, _i, _i, _i, _i, _fp, _i, _i]),
+    "bhip_mean_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _i, _i]),
+    "bhip_median_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _fp, _i, _i]),
     "bhip_corner_intensity_f32": (_i, [_vp, _i, _i, _f, _fp, _fp, _i, _i, _i, _i, _fp, _i, _i]),
     "bhip_brief_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _dp, _i, _i32p]),
 }

@@ -952,7 +952,15 @@ def _conv(fn, kernel, src, dst, ctx):
 
 
 class ConvolveImageNoBorder:
-    """BOverrideConvolveImage.horizontal/vertical targets (I:alg/filter/convolve/ConvolveImageNoBorder.java:53-77)"""
+    """BOverrideConvolveImage.horizontal/vertical/convolve targets (I:alg/filter/convolve/ConvolveImageNoBorder.java:53-90)"""
+
+    @staticmethod
+    def convolve(kernel, input, output, ctx=None):
+        ctx = _ctx(ctx)
+        if output.width != input.width or output.height != input.height:
+            raise IllegalArgumentException("Image shapes do not match")
+        _check(ctx, _lib.load().bhip_conv2d_f32(ctx._h, kernel.data.ctypes.data_as(_lib._fp), kernel.width, kernel.offset, input._p(), input.startIndex,
+                                                input.stride, input.width, input.height, output._p(), output.startIndex, output.stride))
 
     @staticmethod
     def horizontal(kernel, input, output, ctx=None):
@@ -1081,7 +1089,48 @@ class FactoryPyramid:
         return PyramidDiscreteSampleBlur(kernel, sigma, saveOriginalReference, scaleFactors, ctx)
 
 
+@dataclass
+class Kernel2D_F32:
+    """T:struct/convolve/Kernel2D_F32.java: width x width values row-major, offset = origin index along both axes"""
+    data: np.ndarray
+    width: int = 0
+    offset: int = -1
+
+    def __post_init__(self):
+        self.data = np.ascontiguousarray(self.data, dtype=np.float32)
+        self.width = self.data.shape[0]
+        if self.data.ndim != 2 or self.data.shape[1] != self.width:
+            raise IllegalArgumentException("square kernel expected")
+        if self.offset < 0:
+            self.offset = self.width // 2
+
+
 class BlurImageOps:
+    @staticmethod
+    def mean(input, output, radiusX, radiusY=None, storage=None, ctx=None):
+        """BOverrideBlurImageOps.mean target (I:alg/filter/blur/BlurImageOps.java:343-376)"""
+        ctx = _ctx(ctx)
+        radiusY = radiusX if radiusY is None else radiusY
+        if radiusX <= 0 or radiusY <= 0:
+            raise IllegalArgumentException("Radius must be > 0")
+        if output is None:
+            output = GrayF32(input.width, input.height)
+        _check(ctx, _lib.load().bhip_mean_f32(ctx._h, input._p(), input.startIndex, input.stride, input.width, input.height, int(radiusX), int(radiusY),
+                                              output._p(), output.startIndex, output.stride))
+        return output
+
+    @staticmethod
+    def median(input, output, radius, ctx=None):
+        """BOverrideBlurImageOps.median target (I:alg/filter/blur/BlurImageOps.java:752-765)"""
+        ctx = _ctx(ctx)
+        if radius <= 0:
+            raise IllegalArgumentException("Radius must be > 0")
+        if output is None:
+            output = GrayF32(input.width, input.height)
+        _check(ctx, _lib.load().bhip_median_f32(ctx._h, input._p(), input.startIndex, input.stride, input.width, input.height, int(radius), output._p(),
+                                                output.startIndex, output.stride))
+        return output
+
     @staticmethod
     def gaussian(input, output, sigma, radius, storage=None, ctx=None):
         """BOverrideBlurImageOps.gaussian target (I:alg/filter/blur/BlurImageOps.java:406-425)"""

@@ -23,6 +23,9 @@ int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int
 int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out);
 int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dx, const float* dy, int dStride, int width, int height,
 								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride);
+int bhip_launch_conv2d(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStride, int width, int height, float* out, int outStride);
+int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, int width, int height, int radius);
+int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out, int outStride, int width, int height, int radius);
 int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out);
@@ -1052,6 +1055,44 @@ int bhip_pyramid_f32(bhip_ctx* ctx, const float* kernel, int kw, const int* scal
 	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->b.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;
+}
+
+int bhip_conv2d_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride, int width, int height, float* out,
+					int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, width, height);
+	if (!kernel) return bhip_fail(ctx, BHIP_ERR_INVALID, "null kernel");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(uploadImage(ctx, sc->b, out, outStart, outStride, width, height));   // the frame keeps the caller's pixels
+	BHIP_TRY(bhip_launch_conv2d(ctx, kernel, kw, koff, sc->a.as<float>(), width, width, height, sc->b.as<float>(), width));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, width, height);
+}
+int bhip_mean_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, int radiusX, int radiusY, float* out, int outStart,
+				  int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, width, height);
+	if (radiusX <= 0 || radiusY <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Radius must be > 0");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)width * height * 4));
+	BHIP_TRY(bhip_launch_mean(ctx, false, sc->a.as<float>(), sc->b.as<float>(), width, height, radiusX));
+	BHIP_TRY(bhip_launch_mean(ctx, true, sc->b.as<float>(), sc->c.as<float>(), width, height, radiusY));
+	return downloadImage(ctx, sc->c.p, out, outStart, outStride, width, height);
+}
+int bhip_median_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, int radius, float* out, int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, in, inStride, width, height);
+	CHECK_IMG(ctx, out, outStride, width, height);
+	if (radius <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Radius must be > 0");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
+	BHIP_TRY(bhip_launch_median(ctx, sc->a.as<float>(), width, sc->b.as<float>(), width, width, height, radius));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, width, height);
 }
 
 static int gradHost(bhip_ctx* ctx, int kind, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,

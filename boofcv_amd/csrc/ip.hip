@@ -24,7 +24,8 @@ struct ConvParams {
 	int inStride, outStride, width, height;
 	int kw, koff;
 	int unrolled;   // first tap assigns instead of adding to 0
-	int mode;       // 0 = no border (frame untouched), 1 = normalised border, 2 = normalised naive (kernel wider than image)
+	int mode;       // 0 = no border (frame untouched), 1 = normalised border, 2 = normalised naive (kernel wider than image),
+	                // 3 = normalised border pixels only (interior untouched: the mean blur fills it with running sums)
 	float k[BHIP_MAX_TAPS];
 };
 
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 	const float* src = P.in + (long long)y * P.inStride + x;
 	const bool interior = pos >= offL && pos < extent - offR;
 	float result;
+	if (interior && P.mode == 3) return;
 	if (interior && P.mode != 2) {
 		const float* s = src - offL * step;
 		float total;
@@ -487,6 +489,153 @@ int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kapp
 		ProfScope prof(ctx, "k_corner_cols", 4.0 * width * height * 4);
 		hipLaunchKernelGGL(k_corner_cols, dim3((width - 2 * radius + 255) / 256), dim3(256), 0, ctx->stream, P);
 	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+
+// ---------------- remaining BOverride hooks: 2-D convolution, mean blur, median blur ----------------
+// ConvolveImageNoBorder.convolve(Kernel2D_F32)   I:alg/filter/convolve/ConvolveImageNoBorder.java:79-90
+//   unrolled widths 3..11: row sums from 0, added in order   I:.../noborder/ConvolveImageUnrolled_SB_F32_F32.java:592-644
+//   standard: one running total, row-major                   I:.../noborder/ConvolveImageStandard_SB.java:106-134
+#define BHIP_MAX_TAPS2D 441   // 21 x 21
+struct Conv2DParams {
+	const float* in; float* out;
+	int inStride, outStride, width, height, kw, koff, unrolled;
+	float k[BHIP_MAX_TAPS2D];
+};
+__global__ __launch_bounds__(256) void k_conv2d(Conv2DParams P) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	const int oL = P.koff, oR = P.kw - P.koff - 1;
+	if (x < oL || x >= P.width - oR || y < oL || y >= P.height - oR) return;
+	const float* s = P.in + (long long)(y - oL) * P.inStride + (x - oL);
+	float total = 0;
+	if (P.unrolled) {
+		for (int i = 0; i < P.kw; i++) {
+			float rowTotal = 0;
+			for (int j = 0; j < P.kw; j++) rowTotal += s[(long long)i * P.inStride + j] * P.k[i * P.kw + j];
+			total = i == 0 ? rowTotal : total + rowTotal;
+		}
+	} else {
+		int ik = 0;
+		for (int i = 0; i < P.kw; i++)
+			for (int j = 0; j < P.kw; j++) total += s[(long long)i * P.inStride + j] * P.k[ik++];
+	}
+	P.out[(long long)y * P.outStride + x] = total;
+}
+int bhip_launch_conv2d(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStride, int width, int height, float* out, int outStride) {
+	if (kw <= 0 || kw * kw > BHIP_MAX_TAPS2D || koff < 0 || koff >= kw) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "kernel width not supported");
+	Conv2DParams P;
+	P.in = in; P.out = out; P.inStride = inStride; P.outStride = outStride; P.width = width; P.height = height; P.kw = kw; P.koff = koff;
+	P.unrolled = (koff == kw / 2 && kw % 2 == 1 && (kw == 3 || kw == 5 || kw == 7 || kw == 9 || kw == 11)) ? 1 : 0;
+	for (int i = 0; i < kw * kw; i++) P.k[i] = kernel[i];
+	ProfScope prof(ctx, "k_conv2d", 8.0 * width * height);
+	hipLaunchKernelGGL(k_conv2d, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// BlurImageOps.mean -> ConvolveImageMean.horizontal / vertical  I:alg/filter/convolve/ConvolveImageMean.java:55-101
+//   interior: float running sums, total / divisor   I:alg/filter/convolve/noborder/ImplConvolveMean.java:281-357 (single-threaded order)
+//   border: ConvolveNormalized_JustBorder_SB with the table kernel (k_conv mode 3)
+// As in the corner intensity, a row (then a column) is one sequential chain; one thread each.
+__global__ __launch_bounds__(64) void k_mean_rows(const float* __restrict__ in, int inStride, float* __restrict__ out, int outStride, int width, int height, int radius) {
+	const int y = blockIdx.x * blockDim.x + threadIdx.x;
+	if (y >= height) return;
+	const int kw = 2 * radius + 1;
+	const float divisor = (float)kw;
+	const float* r = in + (long long)y * inStride;
+	float* o = out + (long long)y * outStride;
+	float total = 0;
+	for (int i = 0; i < kw; i++) total += r[i];
+	o[radius] = total / divisor;
+	for (int i = kw; i < width; i++) {
+		total -= r[i - kw];
+		total += r[i];
+		o[i - radius] = total / divisor;
+	}
+}
+__global__ __launch_bounds__(256) void k_mean_cols(const float* __restrict__ in, int inStride, float* __restrict__ out, int outStride, int width, int height, int radius) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= width) return;
+	const int kw = 2 * radius + 1;
+	const float divisor = (float)kw;
+	float total = 0;
+	for (int k = 0; k < kw; k++) total += in[(long long)k * inStride + x];
+	out[(long long)radius * outStride + x] = total / divisor;
+	for (int y = radius + 1; y < height - radius; y++) {
+		total = total - in[(long long)(y + radius - kw) * inStride + x];
+		total += in[(long long)(y + radius) * inStride + x];
+		out[(long long)y * outStride + x] = total / divisor;
+	}
+}
+// one direction of the mean blur: dense in / out of the same shape
+int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, int width, int height, int radius) {
+	const int kw = 2 * radius + 1;
+	if (kw > BHIP_MAX_TAPS) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "mean radius not supported");
+	float ker[BHIP_MAX_TAPS];
+	const float val = 1.0f / (float)kw;   // FactoryKernel.table1D_F32(radius, true)
+	for (int i = 0; i < kw; i++) ker[i] = val;
+	const int extent = vertical ? height : width;
+	if (kw > extent) return bhip_launch_conv(ctx, vertical, true, ker, kw, radius, in, width, width, height, out, width);   // ConvolveImageNormalized
+	// border first (k_conv mode 3), then the interior chains
+	{
+		ConvParams P;
+		P.in = in; P.out = out; P.inStride = width; P.outStride = width; P.width = width; P.height = height; P.kw = kw; P.koff = radius;
+		for (int i = 0; i < kw; i++) P.k[i] = ker[i];
+		P.unrolled = 0; P.mode = 3;
+		dim3 grid((width + 255) / 256, height);
+		if (vertical) hipLaunchKernelGGL(k_conv<true>, grid, dim3(256), 0, ctx->stream, P);
+		else hipLaunchKernelGGL(k_conv<false>, grid, dim3(256), 0, ctx->stream, P);
+	}
+	ProfScope prof(ctx, vertical ? "k_mean_cols" : "k_mean_rows", 8.0 * width * height);
+	if (vertical) hipLaunchKernelGGL(k_mean_cols, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, in, width, out, width, width, height, radius);
+	else hipLaunchKernelGGL(k_mean_rows, dim3((height + 63) / 64), dim3(64), 0, ctx->stream, in, width, out, width, width, height, radius);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// BlurImageOps.median(GrayF32) -> ImplMedianSortNaive.process  I:alg/filter/blur/impl/ImplMedianSortNaive.java:97-135: the (count/2)-th order
+// statistic of the window clipped to the image.  16x16 pixel tiles staged in LDS with their halo; each thread finds the window
+// element v with #(w < v) <= k < #(w <= v) -- comparisons only, so the result is the reference's value exactly.
+#define MED_T 16
+__global__ __launch_bounds__(MED_T * MED_T) void k_median(const float* __restrict__ in, int inStride, float* __restrict__ out, int outStride, int width, int height,
+															int radius) {
+	extern __shared__ float tile[];
+	const int TW = MED_T + 2 * radius;
+	const int x0 = blockIdx.x * MED_T - radius, y0 = blockIdx.y * MED_T - radius;
+	for (int i = threadIdx.y * MED_T + threadIdx.x; i < TW * TW; i += MED_T * MED_T) {
+		const int ty = i / TW, tx = i - ty * TW;
+		const int gx = x0 + tx, gy = y0 + ty;
+		tile[i] = (gx >= 0 && gx < width && gy >= 0 && gy < height) ? in[(long long)gy * inStride + gx] : 0.0f;
+	}
+	__syncthreads();
+	const int x = blockIdx.x * MED_T + threadIdx.x, y = blockIdx.y * MED_T + threadIdx.y;
+	if (x >= width || y >= height) return;
+	const int minI = max(0, y - radius) - y0, maxI = min(height, y + radius + 1) - y0;   // tile coordinates
+	const int minJ = max(0, x - radius) - x0, maxJ = min(width, x + radius + 1) - x0;
+	const int count = (maxI - minI) * (maxJ - minJ), k = count / 2;
+	float result = 0;
+	for (int i = minI; i < maxI; i++)
+		for (int j = minJ; j < maxJ; j++) {
+			const float v = tile[i * TW + j];
+			int less = 0, leq = 0;
+			for (int a = minI; a < maxI; a++)
+				for (int b = minJ; b < maxJ; b++) {
+					const float w = tile[a * TW + b];
+					less += w < v ? 1 : 0;
+					leq += w <= v ? 1 : 0;
+				}
+			if (less <= k && k < leq) result = v;
+		}
+	out[(long long)y * outStride + x] = result;
+}
+int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out, int outStride, int width, int height, int radius) {
+	if (radius > 8) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "median radius > 8 is not supported on the GPU");
+	const int TW = MED_T + 2 * radius;
+	ProfScope prof(ctx, "k_median", 8.0 * width * height);
+	hipLaunchKernelGGL(k_median, dim3((width + MED_T - 1) / MED_T, (height + MED_T - 1) / MED_T), dim3(MED_T, MED_T), (size_t)TW * TW * 4, ctx->stream, in, inStride, out,
+					   outStride, width, height, radius);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

@@ -199,6 +199,21 @@ int bhip_conv_norm_v_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, in
  * (I:alg/filter/blur/BlurImageOps.java:406-425), sigmaX==sigmaY / radiusX==radiusY form */
 int bhip_gaussian_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, double sigma, int radius, float* out,
 					  int outStart, int outStride);
+/* BOverrideConvolveImage.convolve target: ConvolveImageNoBorder.convolve(Kernel2D_F32, GrayF32, GrayF32)
+ * (I:alg/filter/convolve/ConvolveImageNoBorder.java:79-90; unrolled widths 3..11 sum every kernel row from 0 and add the row sums,
+ * I:alg/filter/convolve/noborder/ConvolveImageUnrolled_SB_F32_F32.java:592-644; otherwise ConvolveImageStandard_SB.java:106-134).
+ * kernel = kernelWidth x kernelWidth values, row-major; the frame of `out` is left untouched. */
+int bhip_conv2d_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* in, int inStart, int inStride, int width,
+					int height, float* out, int outStart, int outStride);
+/* BOverrideBlurImageOps.mean target: BlurImageOps.mean(GrayF32, out, radiusX, radiusY, storage) (I:alg/filter/blur/BlurImageOps.java:359-376)
+ * = ConvolveImageMean.horizontal then vertical (I:alg/filter/convolve/ConvolveImageMean.java:55-101): float running sums in the
+ * single-threaded order of ImplConvolveMean (I:alg/filter/convolve/noborder/ImplConvolveMean.java:281-357), re-normalised border. */
+int bhip_mean_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, int radiusX, int radiusY, float* out,
+				  int outStart, int outStride);
+/* BOverrideBlurImageOps.median target: BlurImageOps.median(GrayF32, out, radius) (I:alg/filter/blur/BlurImageOps.java:752-765) =
+ * ImplMedianSortNaive.process (I:alg/filter/blur/impl/ImplMedianSortNaive.java:97-135): the (count/2)-th order statistic of the clipped window */
+int bhip_median_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, int radius, float* out, int outStart,
+					int outStride);
 /* GradientSobel.process(GrayF32,derivX,derivY,border) (I:alg/filter/derivative/GradientSobel.java:158-173);
  * border: 0 = null (frame untouched), 1 = ImageBorderValue(0) */
 int bhip_sobel_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart,

@@ -549,6 +549,111 @@ struct PyramidDiscreteSampleBlur {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Remaining BOverride hooks of the boofcv-ip front end: 2-D convolution, mean blur, median blur
+// ------------------------------------------------------------------------------------------------
+// ConvolveImageNoBorder.convolve(Kernel2D_F32, GrayF32, GrayF32)  I:alg/filter/convolve/ConvolveImageNoBorder.java:79-90
+//   unrolled (odd symmetric widths 3..11): every kernel row is summed from 0 on its own and the row sums are added in order
+//     I:alg/filter/convolve/noborder/ConvolveImageUnrolled_SB_F32_F32.java:118-150, 592-644
+//   standard: one running total over the kernel in row-major order   I:.../noborder/ConvolveImageStandard_SB.java:106-134
+// The frame of `dest` (offset pixels) is left untouched.
+inline void convolve2DNoBorder(const float* ker, int kw, int koff, const GrayF32& src, GrayF32& dest) {
+	const bool unrolled = convIsUnrolled(kw, koff);
+	const int width = src.width, height = src.height;
+	const int offsetL = koff, offsetR = kw - koff - 1;
+	for (int y = offsetL; y < height - offsetR; y++)
+		for (int x = offsetL; x < width - offsetR; x++) {
+			float total = 0;
+			if (unrolled) {
+				for (int i = 0; i < kw; i++) {
+					float rowTotal = 0;
+					for (int j = 0; j < kw; j++) rowTotal += src.get(x - offsetL + j, y - offsetL + i) * ker[i * kw + j];
+					if (i == 0) total = rowTotal; else total += rowTotal;
+				}
+			} else {
+				int indexKer = 0;
+				for (int ki = 0; ki < kw; ki++)
+					for (int kj = 0; kj < kw; kj++) total += src.get(x - offsetL + kj, y + ki - offsetL) * ker[indexKer++];
+			}
+			dest.set(x, y, total);
+		}
+}
+// BlurImageOps.mean(GrayF32, out, radiusX, radiusY, storage)  I:alg/filter/blur/BlurImageOps.java:359-376
+//   ConvolveImageMean.horizontal / vertical   I:alg/filter/convolve/ConvolveImageMean.java:55-101
+//   interior: running sums, total / divisor   I:alg/filter/convolve/noborder/ImplConvolveMean.java:281-357
+//   border: ConvolveNormalized_JustBorder_SB with FactoryKernel.table1D_F32(radius, true)
+inline void meanHorizontal(const GrayF32& input, GrayF32& output, int radius) {
+	const int kw = radius * 2 + 1;
+	std::vector<float> ker(kw, 1.0f / kw);
+	if (kw > input.width) { convolveNormalizedHorizontal(ker.data(), kw, radius, input, output); return; }
+	convNormBorderHorizontal(ker.data(), kw, radius, input, output);
+	const float divisor = kw;
+	for (int y = 0; y < input.height; y++) {
+		int indexIn = input.startIndex + input.stride * y;
+		int indexOut = output.startIndex + output.stride * y + radius;
+		float total = 0;
+		int indexEnd = indexIn + kw;
+		for (; indexIn < indexEnd; indexIn++) total += input.data[indexIn];
+		output.data[indexOut++] = total / divisor;
+		indexEnd = indexIn + input.width - kw;
+		for (; indexIn < indexEnd; indexIn++) {
+			total -= input.data[indexIn - kw];
+			total += input.data[indexIn];
+			output.data[indexOut++] = total / divisor;
+		}
+	}
+}
+inline void meanVertical(const GrayF32& input, GrayF32& output, int radius) {
+	const int kw = radius * 2 + 1;
+	std::vector<float> ker(kw, 1.0f / kw);
+	if (kw > input.height) { convolveNormalizedVertical(ker.data(), kw, radius, input, output); return; }
+	convNormBorderVertical(ker.data(), kw, radius, input, output);
+	const int backStep = kw * input.stride;
+	const float divisor = kw;
+	const int y0 = radius, y1 = output.height - radius;
+	std::vector<float> totals(input.width);
+	for (int x = 0; x < input.width; x++) {
+		int indexIn = input.startIndex + (y0 - radius) * input.stride + x;
+		int indexOut = output.startIndex + output.stride * y0 + x;
+		float total = 0;
+		int indexEnd = indexIn + input.stride * kw;
+		for (; indexIn < indexEnd; indexIn += input.stride) total += input.data[indexIn];
+		totals[x] = total;
+		output.data[indexOut] = total / divisor;
+	}
+	for (int y = y0 + 1; y < y1; y++) {
+		int indexIn = input.startIndex + (y + radius) * input.stride;
+		int indexOut = output.startIndex + y * output.stride;
+		for (int x = 0; x < input.width; x++, indexIn++, indexOut++) {
+			float total = totals[x] - input.data[indexIn - backStep];
+			totals[x] = total += input.data[indexIn];
+			output.data[indexOut] = total / divisor;
+		}
+	}
+}
+inline void blurMean(const GrayF32& input, GrayF32& output, int radiusX, int radiusY, GrayF32& storage) {
+	if (radiusX <= 0 || radiusY <= 0) throw std::invalid_argument("Radius must be > 0");
+	meanHorizontal(input, storage, radiusX);
+	meanVertical(storage, output, radiusY);
+}
+// BlurImageOps.median(GrayF32, out, radius) -> ImplMedianSortNaive.process  I:alg/filter/blur/impl/ImplMedianSortNaive.java:97-135:
+// window clipped to the image, median = the (count/2)-th order statistic (QuickSelect.select returns a VALUE, so it is pinned)
+inline void blurMedian(const GrayF32& input, GrayF32& output, int radius) {
+	if (radius <= 0) throw std::invalid_argument("Radius must be > 0");
+	std::vector<float> storage((size_t)(2 * radius + 1) * (2 * radius + 1));
+	for (int y = 0; y < input.height; y++) {
+		int minI = std::max(0, y - radius), maxI = std::min(input.height, y + radius + 1);
+		for (int x = 0; x < input.width; x++) {
+			int minJ = std::max(0, x - radius), maxJ = std::min(input.width, x + radius + 1);
+			int index = 0;
+			for (int i = minI; i < maxI; i++)
+				for (int j = minJ; j < maxJ; j++) storage[index++] = input.get(j, i);
+			std::nth_element(storage.begin(), storage.begin() + index / 2, storage.begin() + index);
+			output.set(x, y, storage[index / 2]);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gradient corner intensity: ImplSsdCorner_F32 (box window, running sums) with the Shi-Tomasi / Harris scores
 //   F:alg/feature/detect/intensity/impl/ImplSsdCornerBox.java:36-51 (border of the intensity image filled with 0)
 //   F:alg/feature/detect/intensity/impl/ImplSsdCorner_F32.java:62-127 horizontal(), :133-196 vertical()

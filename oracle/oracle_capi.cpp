@@ -349,6 +349,15 @@ int orc_ssd_corner(const orc_image* dx, const orc_image* dy, int radius, int kin
 	} catch (const std::exception&) { return -1; }
 	return 0;
 }
+void orc_conv2d(const float* kernel, int kw, int koff, const orc_image* in, const orc_image* out) { GrayF32 o = view(out); convolve2DNoBorder(kernel, kw, koff, view(in), o); }
+int orc_blur_mean(const orc_image* in, const orc_image* out, int radiusX, int radiusY, const orc_image* storage) {
+	try { GrayF32 o = view(out), st = view(storage); blurMean(view(in), o, radiusX, radiusY, st); } catch (const std::exception&) { return -1; }
+	return 0;
+}
+int orc_blur_median(const orc_image* in, const orc_image* out, int radius) {
+	try { GrayF32 o = view(out); blurMedian(view(in), o, radius); } catch (const std::exception&) { return -1; }
+	return 0;
+}
 void orc_subsample(const orc_image* in, const orc_image* out, int skip) { GrayF32 o = view(out); pyramidSubsample(view(in), o, skip); }
 
 }  // extern "C"

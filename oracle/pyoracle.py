@@ -119,6 +119,9 @@ def lib():
             "orc_sobel": (None, [IM, IM, IM, C.c_int, C.c_int]),
             "orc_three": (None, [IM, IM, IM, C.c_int, C.c_int]),
             "orc_subsample": (None, [IM, IM, C.c_int]),
+            "orc_conv2d": (None, [P(C.c_float), C.c_int, C.c_int, IM, IM]),
+            "orc_blur_mean": (C.c_int, [IM, IM, C.c_int, C.c_int, IM]),
+            "orc_blur_median": (C.c_int, [IM, IM, C.c_int]),
             "orc_ssd_corner": (C.c_int, [IM, IM, C.c_int, C.c_int, C.c_float, P(C.c_float)]),
             "orc_conv_down_norm": (C.c_int, [C.c_int, P(C.c_float), C.c_int, IM, IM, C.c_int]),
             "orc_down_max_side": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -386,6 +389,29 @@ def conv(kind, kernel, offset, src, threads=1):
     k, kp = _kernel(kernel)
     out = Gray(src.width, src.height)
     getattr(lib(), "orc_conv_" + kind)(kp, len(k), offset, src.c(), out.c(), threads)
+    return out
+
+
+def conv2d(kernel2d, offset, src, out=None):
+    """ConvolveImageNoBorder.convolve(Kernel2D_F32): the frame of `out` is left untouched."""
+    k = np.ascontiguousarray(kernel2d, dtype=np.float32)
+    assert k.ndim == 2 and k.shape[0] == k.shape[1]
+    out = out or Gray(src.width, src.height)
+    lib().orc_conv2d(_fp(k), k.shape[0], offset, src.c(), out.c())
+    return out
+
+
+def blur_mean(src, radiusX, radiusY=None):
+    out = Gray(src.width, src.height); st = Gray(src.width, src.height)
+    if lib().orc_blur_mean(src.c(), out.c(), radiusX, radiusX if radiusY is None else radiusY, st.c()) != 0:
+        raise ValueError("Radius must be > 0")
+    return out
+
+
+def blur_median(src, radius):
+    out = Gray(src.width, src.height)
+    if lib().orc_blur_median(src.c(), out.c(), radius) != 0:
+        raise ValueError("Radius must be > 0")
     return out
 
 

@@ -508,6 +508,38 @@ def test_pyramid_batched_device_equals_single(api, orc):
             assert np.array_equal(bits(got[b, offs[i]:offs[i] + e.size].reshape(e.shape)), bits(e)), (b, i)
 
 
+def test_mean_median_conv2d_bit_exact(api, orc):
+    """The remaining BOverride hooks: BlurImageOps.mean (float running sums in the reference's order), BlurImageOps.median (order
+    statistic), ConvolveImageNoBorder.convolve (unrolled and standard 2-D forms); sub-images; argument checks."""
+    rand = orc.JavaRandom(77)
+    for (w, h) in [(25, 20), (200, 150), (640, 480), (5, 4)]:
+        img = rand.fillUniform(orc.Gray(w, h), 0, 20)
+        for radius in (1, 2, 3, 4):
+            out = api.BlurImageOps.mean(G(api, img), None, radius)
+            assert np.array_equal(bits(out.array()), bits(orc.blur_mean(img, radius).array())), (w, h, radius, "mean")
+            if radius <= 3 or w * h < 50000:
+                out = api.BlurImageOps.median(G(api, img), None, radius)
+                assert np.array_equal(bits(out.array()), bits(orc.blur_median(img, radius).array())), (w, h, radius, "median")
+        out = api.BlurImageOps.mean(G(api, img), None, 2, 1)
+        assert np.array_equal(bits(out.array()), bits(orc.blur_mean(img, 2, 1).array()))
+        for kw, off in [(3, 1), (5, 2), (7, 3), (4, 1), (2, 0)]:
+            if kw > min(w, h):
+                continue
+            k = (np.arange(kw * kw, dtype=np.float32).reshape(kw, kw) - 3.5) / 11
+            exp = orc.Gray(w, h); exp.buf[:] = 5.0
+            orc.conv2d(k, off, img, exp)
+            o = api.GrayF32(w, h); o.data[:] = 5.0
+            api.ConvolveImageNoBorder.convolve(api.Kernel2D_F32(k, offset=off), G(api, img), o)
+            assert np.array_equal(bits(o.array()), bits(exp.array())), (w, h, kw)
+    sub = img.sub_image_of(3, 2)
+    big = api.GrayF32(w + 8, h + 6); view = big.subimage(4, 3, 4 + w, 3 + h)
+    api.BlurImageOps.mean(G(api, sub), view, 1)
+    assert np.array_equal(bits(view.array()), bits(orc.blur_mean(img, 1).array())) and big.data[0] == 0
+    for bad in (lambda: api.BlurImageOps.mean(G(api, img), None, 0), lambda: api.BlurImageOps.median(G(api, img), None, 0)):
+        with pytest.raises(api.IllegalArgumentException):
+            bad()
+
+
 def test_brief_bit_exact(api, orc):
     sp, cp = orc.brief_definition()  # FactoryBriefDefinition.gaussian2(new Random(123), 16, 512), generated on the host side
     img = orc.noise_image(160, 120, 77)

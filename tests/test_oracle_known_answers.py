@@ -625,3 +625,43 @@ def test_corner_scores_known_values(orc):  # TestShiTomasiCorner_F32 / TestHarri
     st = orc.corner_intensity(dx, dy, 1, "shitomasi")
     # A = 9 * [[4, 6], [6, 9]]: eigenvalues 0 and 117
     assert abs(st[5, 5]) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# Remaining BOverride hooks: 2-D convolution, mean blur, median blur   IT:alg/filter/blur/TestBlurImageOps.java:60-170
+# ---------------------------------------------------------------------------------------------------
+def test_blur_mean_median_and_conv2d(orc):
+    rand = orc.JavaRandom(234)
+    img = rand.fillUniform(orc.Gray(25, 20), 0, 20)   # TestBlurImageOps: 20x25-ish, U[0,20)
+    a = img.array().astype(np.float64)
+    h, w = a.shape
+    for radius in range(1, 5):
+        # mean == normalised table convolution (BlurImageOps test: tolerance 2; the float running sums are far inside it)
+        exp = np.zeros_like(a)
+        for y in range(h):
+            for x in range(w):
+                exp[y, x] = a[max(0, y - radius):y + radius + 1, max(0, x - radius):x + radius + 1].mean()
+        assert np.abs(orc.blur_mean(img, radius).array() - exp).max() < 1e-4
+        # median == the (count/2)-th order statistic of the clipped window
+        med = orc.blur_median(img, radius).array()
+        for y in range(h):
+            for x in range(w):
+                win = np.sort(img.array()[max(0, y - radius):y + radius + 1, max(0, x - radius):x + radius + 1].ravel())
+                assert med[y, x] == win[len(win) // 2]
+    with pytest.raises(ValueError):
+        orc.blur_mean(img, 0)
+    with pytest.raises(ValueError):
+        orc.blur_median(img, 0)
+    # kernel wider than the image falls back to the normalised convolution
+    small = rand.fillUniform(orc.Gray(4, 3), 0, 20)
+    assert np.allclose(orc.blur_mean(small, 3).array(), small.array().mean(), rtol=1e-5)
+    # 2-D convolution: unrolled (3..11) and standard forms agree to float rounding; frame untouched
+    for kw in (3, 5, 4):
+        k = np.arange(1, kw * kw + 1, dtype=np.float32).reshape(kw, kw) / (kw * kw)
+        out = orc.Gray(25, 20); out.buf[:] = -7
+        got = orc.conv2d(k, kw // 2, img, out).array()
+        oL, oR = kw // 2, kw - kw // 2 - 1
+        for y in range(oL, h - oR):
+            for x in range(oL, w - oR):
+                assert abs(got[y, x] - (a[y - oL:y - oL + kw, x - oL:x - oL + kw] * k).sum()) < 1e-3
+        assert got[0, 0] == -7 and got[-1, -1] == -7
