@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (BASELINE config: 256)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu-frames", type=int, default=192, help="frames in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
