@@ -402,7 +402,41 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const int X0 = (x0 - R) * SKIP - G::rFmax - 1, Y0 = (y0 - R) * SKIP - G::rFmax - 1;
-	if (!(P.ablate & 4)) {
+	bool staged = false;
+	if constexpr (SKIP == 2 && (G::IW % 2 == 0)) {
+		// the patch origin is an even column, so with an even row stride every row of the patch is a run of aligned float2 -- half the load
+		// instructions of the scalar path below (this kernel is bound by staging: ~9 k floats per tile); the two halves of a pair go to the two
+		// column-phase planes at the same index
+		if (!(P.ablate & 4) && (stride & 1) == 0 && (W & 1) == 0 && (((unsigned long long)d) & 7ull) == 0) {
+			const int tx = tid & 63, ty = tid >> 6;
+			constexpr int PAIRS = G::IW / 2;
+			static_assert(PAIRS <= 64, "one lane per float2 of a patch row");
+			constexpr int RB = (G::IH + 7) / 8;
+			for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
+				float2 v[RB];
+#pragma unroll
+				for (int k = 0; k < RB; k++) {
+					const int ry = ry0 + 4 * k;
+					const int gy = Y0 + ry;
+					const int gx = X0 + 2 * tx;
+					const bool ok = ry < G::IH && gy >= 0 && gy < H && tx < PAIRS && gx >= 0 && gx < W;
+					const float2* __restrict__ src = (const float2*)(d + (long long)(ok ? gy : 0) * stride + (ok ? gx : 0));
+					v[k] = *src;
+					if (!ok) v[k] = make_float2(0.0f, 0.0f);
+				}
+#pragma unroll
+				for (int k = 0; k < RB; k++) {
+					const int ry = ry0 + 4 * k;
+					if (ry < G::IH && tx < PAIRS) {
+						iiT[ry * G::IWp + tx] = v[k].x;
+						iiT[G::plane + ry * G::IWp + tx] = v[k].y;
+					}
+				}
+			}
+			staged = true;
+		}
+	}
+	if (!staged && !(P.ablate & 4)) {
 		// stage the patch: every thread keeps a batch of independent global loads in flight before the first LDS store
 		const int tx = tid & 63, ty = tid >> 6;
 		constexpr int COLS = (G::IW + 63) / 64;   // 64-float column chunks per row
