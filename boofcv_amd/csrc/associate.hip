@@ -26,6 +26,12 @@ struct RowBest {
 
 #define VT 64  // vectors of the streamed set per LDS tile
 
+// int8 MFMA Hamming path (assoc_ham_mfma.hip)
+int bhip_ham_expand(bhip_ctx* ctx, const int* D, long long rows, int words, unsigned char* bytes, int* pop);
+int bhip_ham_mfma_splits(int nU, int nV);
+int bhip_ham_mfma_scan(bhip_ctx* ctx, bool colMode, const unsigned char* Ub, const int* Up, int nU, const unsigned char* Vb, const int* Vp, int nV, int words,
+						 int vBase, double maxErr, void* partial, int splits);
+
 template <int DOF>
 struct L2Scorer {
 	typedef double elem;
@@ -257,13 +263,36 @@ static int phase1(bhip_ctx* ctx, bool hamming, const E* src, int nsLocal, int sr
 		}
 		return BHIP_OK;
 	}
-	const int rsplits = chooseSplits(nsLocal, nd);
-	const int csplits = colTop ? chooseSplits(nd, nsLocal) : 0;
-	const size_t rowBytes = (size_t)rsplits * nsLocal * sizeof(RowBest);
-	const size_t colBytes = (size_t)csplits * nd * sizeof(ColTop);
-	BHIP_TRY(work.reserve(ctx, rowBytes + colBytes + 64));
+	// BRIEF-512 (16 words) runs on the int8 matrix cores (assoc_ham_mfma.hip: exact integer scores, same partial records);
+	// BHIP_HAM_VALU=1 keeps the popcount scan below (cross-check)
+	static int hamValu = -1;
+	if (hamValu < 0) { const char* e = getenv("BHIP_HAM_VALU"); hamValu = (e && e[0] == '1') ? 1 : 0; }
+	const bool hamMfma = hamming && len == 16 && !hamValu;
+	const int rsplits = hamMfma ? bhip_ham_mfma_splits(nsLocal, nd) : chooseSplits(nsLocal, nd);
+	const int csplits = !colTop ? 0 : hamMfma ? bhip_ham_mfma_splits(nd, nsLocal) : chooseSplits(nd, nsLocal);
+	const size_t rowBytes = ((size_t)rsplits * nsLocal * sizeof(RowBest) + 63) & ~(size_t)63;
+	const size_t colBytes = ((size_t)csplits * nd * sizeof(ColTop) + 63) & ~(size_t)63;
+	const size_t expBytes = hamMfma ? ((size_t)(nsLocal + nd) * (32 * 16 + 4) + 256) : 0;
+	BHIP_TRY(work.reserve(ctx, rowBytes + colBytes + expBytes + 64));
 	RowBest* rowPart = (RowBest*)work.p;
-	ColTop* colPart = (ColTop*)((char*)work.p + ((rowBytes + 63) & ~(size_t)63));
+	ColTop* colPart = (ColTop*)((char*)work.p + rowBytes);
+	if (hamMfma) {
+		unsigned char* srcB = (unsigned char*)work.p + rowBytes + colBytes;
+		unsigned char* dstB = srcB + (size_t)nsLocal * 512;
+		int* srcP = (int*)(dstB + (size_t)nd * 512);
+		int* dstP = srcP + nsLocal;
+		BHIP_TRY(bhip_ham_expand(ctx, (const int*)src, nsLocal, 16, srcB, srcP));
+		BHIP_TRY(bhip_ham_expand(ctx, (const int*)dst, nd, 16, dstB, dstP));
+		BHIP_TRY(bhip_ham_mfma_scan(ctx, false, srcB, srcP, nsLocal, dstB, dstP, nd, 16, 0, maxErr, rowPart, rsplits));
+		hipLaunchKernelGGL(k_merge_rows, dim3((nsLocal + 255) / 256), dim3(256), 0, ctx->stream, (const RowBest*)rowPart, rsplits, nsLocal, maxErr, pairs, fit);
+		BHIP_HIP(ctx, hipGetLastError());
+		if (colTop) {
+			BHIP_TRY(bhip_ham_mfma_scan(ctx, true, dstB, dstP, nd, srcB, srcP, nsLocal, 16, srcBegin, maxErr, colPart, csplits));
+			hipLaunchKernelGGL(k_merge_cols, dim3((nd + 255) / 256), dim3(256), 0, ctx->stream, (const ColTop*)colPart, csplits, nd, colTop);
+			BHIP_HIP(ctx, hipGetLastError());
+		}
+		return BHIP_OK;
+	}
 	if (hamming) BHIP_TRY((scanHam<false>(ctx, (const int*)src, nsLocal, (const int*)dst, nd, len, 0, maxErr, rowPart, rsplits)));
 	else BHIP_TRY((scanL2<false>(ctx, (const double*)src, nsLocal, (const double*)dst, nd, len, 0, maxErr, sqrtScore, rowPart, rsplits)));
 	hipLaunchKernelGGL(k_merge_rows, dim3((nsLocal + 255) / 256), dim3(256), 0, ctx->stream, (const RowBest*)rowPart, rsplits, nsLocal, maxErr, pairs, fit);
