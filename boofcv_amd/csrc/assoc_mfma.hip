@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int r = lane & 31, h = lane >> 5;
 	const int rowT = B.row0 + 32 * wave;  // first row of this wave's tile
-	if (rowT >= P.ns) return;
+	const bool live = rowT < P.ns;        // a wave without rows still stages B tiles and meets the barriers
 	CandStage S;
 	S.buf = candLds[wave];
 	S.cnt[0] = 0;
@@ -191,39 +191,59 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 		else rowV[g] = ok ? A.rowThr[P.rowBase + rr] : -INFINITY;
 	}
 
-	// B fragments are software-pipelined: the loads of step k+1 are issued before the MFMAs of step k, so their latency (an L2 /
-	// Infinity-Cache round trip, comparable to the 64 MFMAs of a step) overlaps the matrix work instead of preceding it
-	float b0[32], b1[32];
-	auto loadB = [&](int c0, float (&d0)[32], float (&d1)[32]) {
-		const int colA = c0 + r, colB = c0 + 32 + r;
-		const bool okA = colA < B.col1, okB = colB < B.col1;
-		const f32x4* s0 = (const f32x4*)(A.Fd + ((long long)(P.dstOff + (okA ? colA : 0)) * 64 + 32 * h));
-		const f32x4* s1 = (const f32x4*)(A.Fd + ((long long)(P.dstOff + (okB ? colB : 0)) * 64 + 32 * h));
+	// The four waves of a block sweep the same destination columns, so every 64-column step of B is staged ONCE per block in LDS
+	// (fp32 rows as 16-byte chunks, [tile][chunk][column] with a pitch of 33 chunks: fragment reads are contiguous across lanes) and
+	// double-buffered: the next step's chunks are fetched into registers before this step's MFMAs and stored after them.  One L2 read
+	// of B per block instead of four, and its latency sits behind the matrix work.
+	__shared__ uint4 tileB[2][2][16 * 33];
+	const int tid = threadIdx.x;
+	uint4 pre[4];
+	auto fetch = [&](int c0) {
 #pragma unroll
-		for (int q = 0; q < 8; q++) {
-			const f32x4 v = s0[q], w = s1[q];
-			d0[4 * q] = v.x; d0[4 * q + 1] = v.y; d0[4 * q + 2] = v.z; d0[4 * q + 3] = v.w;
-			d1[4 * q] = w.x; d1[4 * q + 1] = w.y; d1[4 * q + 2] = w.z; d1[4 * q + 3] = w.w;
+		for (int q = 0; q < 4; q++) {
+			const int g = tid + 256 * q;          // 2 tiles x 32 columns x 16 chunks
+			const int col = c0 + (g >> 4);        // (g >> 9) * 32 + ((g & 511) >> 4) == g >> 4
+			pre[q] = col < B.col1 ? ((const uint4*)(A.Fd + (long long)(P.dstOff + col) * 64))[g & 15] : make_uint4(0, 0, 0, 0);
 		}
 	};
-	loadB(B.col0, b0, b1);
-	for (int c0 = B.col0; c0 < B.col1; c0 += 64) {
+	auto stash = [&](int buf) {
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const int g = tid + 256 * q;
+			tileB[buf][g >> 9][(g & 15) * 33 + ((g & 511) >> 4)] = pre[q];
+		}
+	};
+	fetch(B.col0);
+	stash(0);
+	__syncthreads();
+	int buf = 0;
+	for (int c0 = B.col0; c0 < B.col1; c0 += 64, buf ^= 1) {
 		const int colA = c0 + r, colB = c0 + 32 + r;
 		const bool okA = colA < B.col1, okB = colB < B.col1;
-		// pass 1 has the registers to hold the next step's fragments; pass 2 (thresholds + candidate staging) does not and loads in place
-		float n0[PASS == 1 ? 32 : 1], n1[PASS == 1 ? 32 : 1];
-		const bool more = c0 + 64 < B.col1;   // wave-uniform
-		if constexpr (PASS == 1) { if (more) loadB(c0 + 64, n0, n1); }
-		else { if (c0 != B.col0) loadB(c0, b0, b1); }
+		const bool more = c0 + 64 < B.col1;   // block-uniform
+		if (more) fetch(c0 + 64);
 		const float nbA = okA ? A.nrmD[P.dstOff + colA] : INFINITY;
 		const float nbB = okB ? A.nrmD[P.dstOff + colB] : INFINITY;
 		f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		f32x16 acc1 = acc0;
+		// lane (r, h) needs k in [32h, 32h+32) of columns colA / colB = chunks 8h .. 8h+7; two halves keep 32 B registers live, not 64
 #pragma unroll
-		for (int s = 0; s < 32; s++) {
-			acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], acc1, 0, 0, 0);
+		for (int half = 0; half < 2; half++) {
+			float b0[16], b1[16];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const uint4 v = tileB[buf][0][(8 * h + 4 * half + q) * 33 + r], w = tileB[buf][1][(8 * h + 4 * half + q) * 33 + r];
+				b0[4 * q] = __uint_as_float(v.x); b0[4 * q + 1] = __uint_as_float(v.y); b0[4 * q + 2] = __uint_as_float(v.z); b0[4 * q + 3] = __uint_as_float(v.w);
+				b1[4 * q] = __uint_as_float(w.x); b1[4 * q + 1] = __uint_as_float(w.y); b1[4 * q + 2] = __uint_as_float(w.z); b1[4 * q + 3] = __uint_as_float(w.w);
+			}
+#pragma unroll
+			for (int s = 0; s < 16; s++) {
+				acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[16 * half + s], b0[s], acc0, 0, 0, 0);
+				acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[16 * half + s], b1[s], acc1, 0, 0, 0);
+			}
 		}
+		if (more) stash(buf ^ 1);   // the other buffer was last read before the previous barrier
+		if (live) {
 		if (PASS == 1) {
 			float cA = INFINITY, cB = INFINITY;
 #pragma unroll
@@ -268,13 +288,10 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 				}
 			}
 		}
-		if constexpr (PASS == 1) {
-			if (more) {
-#pragma unroll
-				for (int q = 0; q < 32; q++) { b0[q] = n0[q]; b1[q] = n1[q]; }
-			}
-		}
+		}   // live
+		__syncthreads();
 	}
+	if (!live) return;
 	if (PASS == 2) {
 		candFlush(A, S, 0, lane);
 		candFlush(A, S, 1, lane);
@@ -385,6 +402,7 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	long long rowBlocks = 0;
 	for (int p = 0; p < count; p++) rowBlocks += (ns[p] + 127) / 128;
 	int colSplit = (int)std::max<long long>(1, (1024 + rowBlocks - 1) / rowBlocks);
+	{ const char* e = getenv("BHIP_ASSOC_COLSPLIT"); if (e && atoi(e) > 0) colSplit = atoi(e); }   // tests: force long column sweeps per block
 	for (int p = 0; p < count; p++) {
 		int split = std::min(colSplit, (nd[p] + 63) / 64);
 		int per = (nd[p] + split - 1) / split;

@@ -591,6 +591,26 @@ def test_mfma_association_config3_and_tie_stress(api, orc):
             assert np.array_equal(a.getPairs(), p) and np.array_equal(a.getFitQuality(), f)
 
 
+def test_mfma_association_long_sweeps(api, orc, tmp_path):
+    """One block sweeping many 64-column steps (the double-buffered LDS tiles of the fp32 MFMA kernel): a single problem normally has its
+    columns split over many blocks, so the split is forced to 1 in a child process (BHIP_ASSOC_COLSPLIT) and compared with the oracle."""
+    import os, subprocess, sys
+    rng = np.random.default_rng(3)
+    src = _surf_like(rng, 1500); dst = _surf_like(rng, 1300)
+    dst[:800] = src[100:900] + rng.normal(scale=0.02, size=(800, 64)); dst[900] = dst[10]
+    np.save(tmp_path / "s.npy", src); np.save(tmp_path / "d.npy", dst)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from boofcv_amd import api; "
+            "a = api.FactoryAssociation.greedy(api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True); "
+            "a.setSource(np.load(%r)); a.setDestination(np.load(%r)); a.associate(); np.save(%r, a.getPairs()); np.save(%r, a.getFitQuality())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e["BHIP_ASSOC_COLSPLIT"] = "1"
+    subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "s.npy"), str(tmp_path / "d.npy"), str(tmp_path / "p.npy"), str(tmp_path / "f.npy"))],
+                   check=True, env=e, timeout=300)
+    ep, ef = orc.associate_l2(src, dst, orc.MAX_VALUE_F64, True, threads=8)
+    assert np.array_equal(np.load(tmp_path / "p.npy"), ep) and np.array_equal(np.load(tmp_path / "f.npy"), ef)
+    assert (ep >= 0).sum() > 700
+
+
 def test_mfma_association_degenerate_inputs_fall_back(api, orc):
     z = np.zeros((300, 64)); one = np.tile(_surf_like(np.random.default_rng(0), 1), (260, 1))
     for src, dst in [(z, z), (one, one), (z, one)]:  # every pair is a candidate: list overflow -> exact path
