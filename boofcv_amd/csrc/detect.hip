@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 	const int x = b + blockIdx.x * blockDim.x + threadIdx.x;
 	const int yBase = b + blockIdx.y * NMS_ROWS;
 	const int img = blockIdx.z;
-	if (x >= w - b) return;
 	const float* mid = P.mid + (long long)img * P.imageStride;
 	const int stride = P.stride;
 	const int r = P.radius;
@@ -84,63 +83,80 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 #pragma unroll
 	for (int k = 0; k < NMS_ROWS + 2; k++) {
 		const int yy = yBase - 1 + k;
-		col[k] = (yy >= 0 && yy < h) ? mid[(long long)yy * stride + x] : -INFINITY;
+		col[k] = (yy >= 0 && yy < h && x < w - b) ? mid[(long long)yy * stride + x] : -INFINITY;
 	}
 #pragma unroll
 	for (int k = 0; k < NMS_ROWS; k++) {
 		const int yy = yBase + k;
-		const bool rowIn = yy < h;
+		const bool rowIn = yy < h && x < w - b;
 		lf[k] = (rowIn && x >= 1) ? mid[(long long)yy * stride + x - 1] : -INFINITY;
 		rt[k] = (rowIn && x + 1 < w) ? mid[(long long)yy * stride + x + 1] : -INFINITY;
 	}
-#pragma unroll 1
-	for (int k = 0; k < NMS_ROWS; k++) {
-	const int y = yBase + k;
-	if (y >= h - b) break;
-	const float val = col[k + 1];
-	if (!(val >= P.threshold) || val == FLT_MAX) continue;
-	// most pixels above the threshold lose against a direct neighbour (r >= 1, so the four are inside the strict-max window)
-	if (lf[k] >= val || rt[k] >= val || col[k] >= val || col[k + 2] >= val) continue;
-	if (!(r == 2 ? strictLocalMax<2>(mid, stride, w, h, x, y, r, val, P.threshold) : strictLocalMax<0>(mid, stride, w, h, x, y, r, val, P.threshold))) continue;
-
-	// findLocalScaleSpaceMax: candidates hugging the ignore border are dropped
-	const int ignoreR = b + r;
-	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) continue;
-	const float* lower = P.lower + (long long)img * P.imageStride;
-	const float* upper = P.upper + (long long)img * P.imageStride;
-	// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
-	bool below = true;
+	// Survivors of the cheap tests are rare (a few per cent) but almost every wave has one, so running the full-window test in place
+	// would make every wave walk the expensive path with one or two active lanes.  They are compacted into a block-wide list first
+	// and then tested densely, one candidate per thread.  (The output order is fixed later by the bitmap, not by emission order.)
+	__shared__ int candList[256 * NMS_ROWS];
+	__shared__ int candCount;
+	if (threadIdx.x == 0) candCount = 0;
+	__syncthreads();
+	if (x < w - b) {
 #pragma unroll
-	for (int j = y - 1; j <= y + 1; j++)
-#pragma unroll
-		for (int i = x - 1; i <= x + 1; i++) {
-			const bool in = i >= 0 && i < w && j >= 0 && j < h;
-			const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
-			const float up = in ? upper[(long long)j * stride + i] : 0.0f;
-			if (lo >= val || up >= val) below = false;
+		for (int k = 0; k < NMS_ROWS; k++) {
+			const int y = yBase + k;
+			const float val = col[k + 1];
+			const bool pass = y < h - b && val >= P.threshold && val != FLT_MAX &&
+							  // most pixels above the threshold lose against a direct neighbour (r >= 1, so the four are inside the strict-max window)
+							  !(lf[k] >= val || rt[k] >= val || col[k] >= val || col[k + 2] >= val);
+			if (pass) candList[atomicAdd(&candCount, 1)] = (k << 16) | (int)threadIdx.x;
 		}
-	if (!below) continue;
-	const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
-	const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
-	const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
-	const float interpX = ((float)x + peakX) * (float)P.p.skip;
-	const float interpY = ((float)y + peakY) * (float)P.p.skip;
-	const float interpS = (float)P.p.sizeMid + peakS * (float)(P.p.sizeMid - P.p.sizeLower);
-	const double scale = 1.2 * (double)interpS / 9.0;
-
-	const int step = r + 1;
-	const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
-	atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
-	const int slot = atomicAdd(&P.candCount[img], 1);
-	if (slot < P.cap) {
-		KeyPoint kp;
-		kp.x = (double)interpX;
-		kp.y = (double)interpY;
-		kp.scale = scale;
-		kp.key = bit;
-		kp.pad = 0;
-		P.cand[(long long)img * P.cap + slot] = kp;
 	}
+	__syncthreads();
+	const int ncand = candCount;
+	for (int ci = threadIdx.x; ci < ncand; ci += blockDim.x) {
+		const int code = candList[ci];
+		const int x = b + blockIdx.x * blockDim.x + (code & 0xFFFF);
+		const int y = yBase + (code >> 16);
+		const float val = mid[(long long)y * stride + x];
+		if (!(r == 2 ? strictLocalMax<2>(mid, stride, w, h, x, y, r, val, P.threshold) : strictLocalMax<0>(mid, stride, w, h, x, y, r, val, P.threshold))) continue;
+
+		// findLocalScaleSpaceMax: candidates hugging the ignore border are dropped
+		const int ignoreR = b + r;
+		if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) continue;
+		const float* lower = P.lower + (long long)img * P.imageStride;
+		const float* upper = P.upper + (long long)img * P.imageStride;
+		// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
+		bool below = true;
+#pragma unroll
+		for (int j = y - 1; j <= y + 1; j++)
+#pragma unroll
+			for (int i = x - 1; i <= x + 1; i++) {
+				const bool in = i >= 0 && i < w && j >= 0 && j < h;
+				const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
+				const float up = in ? upper[(long long)j * stride + i] : 0.0f;
+				if (lo >= val || up >= val) below = false;
+			}
+		if (!below) continue;
+		const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
+		const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
+		const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
+		const float interpX = ((float)x + peakX) * (float)P.p.skip;
+		const float interpY = ((float)y + peakY) * (float)P.p.skip;
+		const float interpS = (float)P.p.sizeMid + peakS * (float)(P.p.sizeMid - P.p.sizeLower);
+		const double scale = 1.2 * (double)interpS / 9.0;
+
+		const int step = r + 1;
+		const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
+		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+		const int slot = atomicAdd(&P.candCount[img], 1);
+		if (slot < P.cap) {
+			KeyPoint kp;
+			kp.x = (double)interpX;
+			kp.y = (double)interpY;
+			kp.scale = scale;
+			kp.key = bit;
+			kp.pad = 0;
+			P.cand[(long long)img * P.cap + slot] = kp;
+		}
 	}
 }
 
