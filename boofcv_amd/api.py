@@ -171,6 +171,53 @@ class TupleDesc_F64:
         self.value = np.array(src.value, dtype=np.float64)
 
 
+class _GrayInt:
+    """Integer single-band images (T:struct/image/GrayU8.java, GrayS32.java): pixel (x,y) = data[startIndex + y*stride + x]."""
+    dtype = None
+
+    def __init__(self, width=0, height=0, data=None, startIndex=0, stride=None):
+        self.width, self.height = int(width), int(height)
+        self.stride = int(width if stride is None else stride)
+        self.startIndex = int(startIndex)
+        if data is None:
+            data = np.zeros(self.startIndex + self.stride * self.height, dtype=self.dtype)
+        if data.dtype != self.dtype or not data.flags["C_CONTIGUOUS"] or data.ndim != 1:
+            raise IllegalArgumentException("data must be a contiguous 1-D %s array" % np.dtype(self.dtype).name)
+        self.data = data
+
+    @classmethod
+    def wrap(cls, a):
+        a = np.ascontiguousarray(a, dtype=cls.dtype)
+        return cls(a.shape[1], a.shape[0], a.reshape(-1))
+
+    def reshape(self, width, height):
+        if width * height > self.data.size or self.startIndex != 0:
+            self.data = np.zeros(width * height, dtype=self.dtype)
+            self.startIndex = 0
+        self.width, self.height, self.stride = int(width), int(height), int(width)
+
+    def subimage(self, x0, y0, x1, y1):
+        return type(self)(x1 - x0, y1 - y0, self.data, self.startIndex + y0 * self.stride + x0, self.stride)
+
+    def array(self):
+        it = np.dtype(self.dtype).itemsize
+        return np.lib.stride_tricks.as_strided(self.data[self.startIndex:], shape=(self.height, self.width), strides=(it * self.stride, it))
+
+
+class GrayU8(_GrayInt):
+    dtype = np.uint8
+
+    def _p(self):
+        return self.data.ctypes.data_as(_lib._u8p)
+
+
+class GrayS32(_GrayInt):
+    dtype = np.int32
+
+    def _p(self):
+        return self.data.ctypes.data_as(_lib._i32p)
+
+
 class Planar:
     """T:struct/image/Planar.java: bands of one shape.  Planar(GrayF32, width, height, numBands) or Planar.wrap([bands])."""
 
@@ -761,6 +808,17 @@ class IntegralImageOps:
     def transform(input, transformed=None, ctx=None):
         """GIntegralImageOps.transform (I:alg/transform/ii/GIntegralImageOps.java:55-70)"""
         ctx = _ctx(ctx)
+        if isinstance(input, GrayU8):
+            # transform(GrayU8, GrayS32) (I:alg/transform/ii/impl/ImplIntegralImageOps.java:94-118)
+            if transformed is None:
+                transformed = GrayS32(input.width, input.height)
+            elif not isinstance(transformed, GrayS32):
+                raise IllegalArgumentException("GrayU8 is transformed into GrayS32")
+            elif transformed.width != input.width or transformed.height != input.height:
+                transformed.reshape(input.width, input.height)
+            _check(ctx, _lib.load().bhip_integral_u8_s32(ctx._h, input._p(), input.startIndex, input.stride, input.width, input.height, transformed._p(),
+                                                         transformed.startIndex, transformed.stride))
+            return transformed
         if transformed is None:
             transformed = GrayF32(input.width, input.height)
         elif transformed.width != input.width or transformed.height != input.height:
@@ -775,6 +833,10 @@ class IntegralImageFeatureIntensity:
     def hessian(integral, skip, size, intensity, ctx=None):
         """F:alg/feature/detect/intensity/IntegralImageFeatureIntensity.java:43-56; intensity must be (width/skip) x (height/skip)."""
         ctx = _ctx(ctx)
+        if isinstance(integral, GrayS32):
+            _check(ctx, _lib.load().bhip_hessian_s32(ctx._h, integral._p(), integral.startIndex, integral.stride, integral.width, integral.height, skip, size,
+                                                     intensity._p(), intensity.startIndex, intensity.stride))
+            return
         _check(ctx, _lib.load().bhip_hessian_f32(ctx._h, integral._p(), integral.startIndex, integral.stride, integral.width, integral.height, skip, size,
                                                  intensity._p(), intensity.startIndex, intensity.stride))
 
@@ -1184,6 +1246,11 @@ class DescribePointBrief:
         n, npts = len(xy), len(self.compare)
         out = np.zeros((n, (npts + 31) // 32), dtype=np.int32)
         im = self.image
+        if isinstance(im, GrayU8):   # ImplDescribeBinaryCompare_U8
+            _check(self.ctx, _lib.load().bhip_brief_u8(self.ctx._h, im._p(), im.startIndex, im.stride, im.width, im.height, self.radius, npts,
+                                                      self.samplePoints.ctypes.data_as(_lib._i32p), self.compare.ctypes.data_as(_lib._i32p),
+                                                      xy.ctypes.data_as(_lib._dp), n, out.ctypes.data_as(_lib._i32p)))
+            return out
         _check(self.ctx, _lib.load().bhip_brief_f32(self.ctx._h, im._p(), im.startIndex, im.stride, im.width, im.height, self.radius, npts,
                                                    self.samplePoints.ctypes.data_as(_lib._i32p), self.compare.ctypes.data_as(_lib._i32p),
                                                    xy.ctypes.data_as(_lib._dp), n, out.ctypes.data_as(_lib._i32p)))

@@ -28,7 +28,8 @@ int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, 
 int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out, int outStride, int width, int height, int radius);
 int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
-					  const int* compare, const double* xy, int n, int* out);
+					  const int* compare, const double* xy, int n, int* out, bool u8 = false);
+int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, int inStride, int* out, int outStride, int width, int height);
 
 int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* dev_src, const double* dev_dst, int count, const long long* srcOff,
 								 const int* ns, const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit,
@@ -1138,6 +1139,59 @@ int bhip_corner_intensity_f32(bhip_ctx* ctx, int kind, int radius, float kappa, 
 	BHIP_TRY(bhip_launch_corner_intensity(ctx, kind, radius, kappa, sc->a.as<float>(), sc->b.as<float>(), width, width, height, h, h + px, h + 2 * px,
 										  sc->d.as<float>(), width));
 	return downloadImage(ctx, sc->d.p, intensity, iStart, iStride, width, height);
+}
+
+// ---- integer image variants, stage level ----
+int bhip_integral_u8_s32(bhip_ctx* ctx, const uint8_t* in, int inStart, int inStride, int width, int height, int32_t* out, int outStart, int outStride) {
+	CHECK_CTX(ctx);
+	if (!in || !out || width <= 0 || height <= 0 || inStride < width || outStride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(sc->a.reserve(ctx, (size_t)width * height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
+	BHIP_HIP(ctx, hipMemcpy2DAsync(sc->a.p, (size_t)width, in + inStart, (size_t)inStride, (size_t)width, height, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_TRY(bhip_launch_integral_u8(ctx, (const unsigned char*)sc->a.p, width, sc->b.as<int>(), width, width, height));
+	BHIP_HIP(ctx, hipMemcpy2DAsync(out + outStart, (size_t)outStride * 4, sc->b.p, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+int bhip_hessian_s32(bhip_ctx* ctx, const int32_t* ii, int iiStart, int iiStride, int width, int height, int skip, int size, float* out, int outStart,
+					 int outStride) {
+	CHECK_CTX(ctx);
+	if (!ii || !out || width <= 0 || height <= 0 || iiStride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image");
+	if (skip < 1 || size < 3) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad skip / size");
+	const int w = width / skip, h = height / skip;
+	if (w <= 0 || h <= 0 || outStride < w) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad intensity image");
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, (const float*)ii, iiStart, iiStride, width, height));   // 32-bit words either way
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)w * h * 4));
+	ImgView iv{sc->a.as<float>(), (long long)width * height, width, width, height};
+	BHIP_TRY(bhip_launch_hessian(ctx, iv, 1, skip, 1, &size, sc->b.as<float>(), (long long)w * h, (long long)w * h, w, nullptr, true));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, w, h);
+}
+int bhip_brief_u8(bhip_ctx* ctx, const uint8_t* img, int start, int stride, int width, int height, int radius, int numPoints, const int32_t* samplePoints,
+				  const int32_t* compare, const double* xy, int n, int32_t* out) {
+	CHECK_CTX(ctx);
+	if (!img || width <= 0 || height <= 0 || stride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image");
+	if (numPoints <= 0 || !samplePoints || !compare || n < 0 || (n > 0 && (!xy || !out))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad BRIEF arguments");
+	if (n == 0) return BHIP_OK;
+	int maxIdx = 0;
+	for (int i = 0; i < 2 * numPoints; i++) { if (compare[i] < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "negative sample index"); maxIdx = std::max(maxIdx, compare[i]); }
+	const int words = (numPoints + 31) / 32;
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(sc->a.reserve(ctx, (size_t)width * height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)(maxIdx + 1) * 8 + (size_t)numPoints * 8));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)n * 16));
+	BHIP_TRY(sc->d.reserve(ctx, (size_t)n * words * 4));
+	BHIP_HIP(ctx, hipMemcpy2DAsync(sc->a.p, (size_t)width, img + start, (size_t)stride, (size_t)width, height, hipMemcpyHostToDevice, ctx->stream));
+	int* dSample = sc->b.as<int>();
+	int* dCompare = dSample + 2 * (maxIdx + 1);
+	BHIP_HIP(ctx, hipMemcpyAsync(dSample, samplePoints, (size_t)(maxIdx + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(dCompare, compare, (size_t)numPoints * 8, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(sc->c.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_TRY(bhip_launch_brief(ctx, (const float*)sc->a.p, width, width, height, radius, numPoints, dSample, dCompare, sc->c.as<double>(), n, sc->d.as<int>(), true));
+	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->d.p, (size_t)n * words * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
 }
 
 int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int width, int height, int radius, int numPoints,

@@ -148,7 +148,7 @@ struct HessLevelSource {
 	int step;                // 1: src already has this octave's layout, 2: take every second pixel
 };
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
-						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr);
+						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr, bool intTaps = false);
 
 // colour SURF request for the describe kernel (see DescParams)
 struct DescPlanar {

@@ -29,7 +29,10 @@ struct HessParams {
 	HessLevelSource from[BHIP_MAX_LEVELS];
 };
 
-__device__ __forceinline__ float block_zero(const float* __restrict__ d, int stride, int W, int H, int x0, int y0, int x1, int y1) {
+// T = float (GrayF32 integral image) or int (GrayS32: exact integer box sums, converted where the reference converts -- at the
+// assignment / compound assignment into a float: ImplIntegralImageFeatureIntensity.java:245-390)
+template <class T>
+__device__ __forceinline__ T block_zero(const T* __restrict__ d, int stride, int W, int H, int x0, int y0, int x1, int y1) {
 	x0 = min(x0, W - 1);
 	y0 = min(y0, H - 1);
 	x1 = min(x1, W - 1);
@@ -37,15 +40,16 @@ __device__ __forceinline__ float block_zero(const float* __restrict__ d, int str
 	// branch-free: the four corners are always fetched (from coordinates clamped into the image) and zeroed afterwards, so the
 	// 40 taps of a border pixel are independent loads in flight together
 	const int cx0 = max(x0, 0), cy0 = max(y0, 0), cx1 = max(x1, 0), cy1 = max(y1, 0);
-	const float vbr = d[(long long)cy1 * stride + cx1], vtr = d[(long long)cy0 * stride + cx1];
-	const float vbl = d[(long long)cy1 * stride + cx0], vtl = d[(long long)cy0 * stride + cx0];
-	const float br = (x1 >= 0 && y1 >= 0) ? vbr : 0.0f;
-	const float tr = (y0 >= 0 && x1 >= 0) ? vtr : 0.0f;
-	const float bl = (x0 >= 0 && y1 >= 0) ? vbl : 0.0f;
-	const float tl = (x0 >= 0 && y0 >= 0) ? vtl : 0.0f;
+	const T vbr = d[(long long)cy1 * stride + cx1], vtr = d[(long long)cy0 * stride + cx1];
+	const T vbl = d[(long long)cy1 * stride + cx0], vtl = d[(long long)cy0 * stride + cx0];
+	const T br = (x1 >= 0 && y1 >= 0) ? vbr : T(0);
+	const T tr = (y0 >= 0 && x1 >= 0) ? vtr : T(0);
+	const T bl = (x0 >= 0 && y1 >= 0) ? vbl : T(0);
+	const T tl = (x0 >= 0 && y0 >= 0) ? vtl : T(0);
 	return br - tr - bl + tl;
 }
 
+template <class T>
 __global__ __launch_bounds__(256) void k_hessian(HessParams P) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	const int y = blockIdx.y;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void k_hessian(HessParams P) {
 		return;
 	}
 	const HessLevel L = P.lv[level];
-	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
+	const T* __restrict__ d = (const T*)P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride;
 	const int skip = P.skip;
 	const int xx = x * skip, yy = y * skip;
@@ -72,42 +76,42 @@ __global__ __launch_bounds__(256) void k_hessian(HessParams P) {
 		const long long top = (long long)(yy - L.rS - 1) * stride + col;
 		const long long bot = top + (long long)L.bL * stride;
 		const int bS = L.bS;
-		Dxx = d[bot + 3 * bS] - d[top + 3 * bS] - d[bot] + d[top];
-		Dxx -= 3 * (d[bot + 2 * bS] - d[top + 2 * bS] - d[bot + bS] + d[top + bS]);
+		Dxx = (float)(d[bot + 3 * bS] - d[top + 3 * bS] - d[bot] + d[top]);
+		Dxx -= (float)(T(3) * (d[bot + 2 * bS] - d[top + 2 * bS] - d[bot + bS] + d[top + bS]));
 
 		const long long l = (long long)(yy - L.rF - 1) * stride + (L.rF - L.rS) + col;
 		const long long r = l + L.bL;
 		const long long ro1 = (long long)bS * stride;
-		Dyy = d[r + 3 * ro1] - d[l + 3 * ro1] - d[r] + d[l];
-		Dyy -= 3 * (d[r + 2 * ro1] - d[l + 2 * ro1] - d[r + ro1] + d[l + ro1]);
+		Dyy = (float)(d[r + 3 * ro1] - d[l + 3 * ro1] - d[r] + d[l]);
+		Dyy -= (float)(T(3) * (d[r + 2 * ro1] - d[l + 2 * ro1] - d[r + ro1] + d[l + ro1]));
 
 		const long long y1 = (long long)(yy - bS - 1) * stride + (L.rF - bS) + col;
 		const long long y2 = y1 + ro1;
 		const long long y3 = y2 + stride;
 		const long long y4 = y3 + ro1;
 		const int x3 = bS + 1, x4 = x3 + bS;
-		Dxy = d[y2 + bS] - d[y1 + bS] - d[y2] + d[y1];
-		Dxy -= d[y2 + x4] - d[y1 + x4] - d[y2 + x3] + d[y1 + x3];
-		Dxy += d[y4 + x4] - d[y3 + x4] - d[y4 + x3] + d[y3 + x3];
-		Dxy -= d[y4 + bS] - d[y3 + bS] - d[y4] + d[y3];
+		Dxy = (float)(d[y2 + bS] - d[y1 + bS] - d[y2] + d[y1]);
+		Dxy -= (float)(d[y2 + x4] - d[y1 + x4] - d[y2 + x3] + d[y1 + x3]);
+		Dxy += (float)(d[y4 + x4] - d[y3 + x4] - d[y4 + x3] + d[y3 + x3]);
+		Dxy -= (float)(d[y4 + bS] - d[y3 + bS] - d[y4] + d[y3]);
 	} else {
-		// computeHessian via convolveSparse: ret = 0; ret += block_zero(...) * (float)scale, block by block
+		// computeHessian via convolveSparse: ret = 0; ret += block_zero(...) * scale, block by block (float scales for GrayF32, int for GrayS32)
 		const int W = P.ii.width, H = P.ii.height;
-		float ret = 0;
-		ret += block_zero(d, stride, W, H, xx - L.r2 - 1, yy - L.r3 - 1, xx + L.r2, yy + L.r3) * 1.0f;
-		ret += block_zero(d, stride, W, H, xx - L.r1 - 1, yy - L.r3 - 1, xx + L.r1, yy + L.r3) * -3.0f;
-		Dxx = ret;
+		T ret = 0;
+		ret += block_zero<T>(d, stride, W, H, xx - L.r2 - 1, yy - L.r3 - 1, xx + L.r2, yy + L.r3) * T(1);
+		ret += block_zero<T>(d, stride, W, H, xx - L.r1 - 1, yy - L.r3 - 1, xx + L.r1, yy + L.r3) * T(-3);
+		Dxx = (float)ret;
 		ret = 0;
-		ret += block_zero(d, stride, W, H, xx - L.r3 - 1, yy - L.r2 - 1, xx + L.r3, yy + L.r2) * 1.0f;
-		ret += block_zero(d, stride, W, H, xx - L.r3 - 1, yy - L.r1 - 1, xx + L.r3, yy + L.r1) * -3.0f;
-		Dyy = ret;
+		ret += block_zero<T>(d, stride, W, H, xx - L.r3 - 1, yy - L.r2 - 1, xx + L.r3, yy + L.r2) * T(1);
+		ret += block_zero<T>(d, stride, W, H, xx - L.r3 - 1, yy - L.r1 - 1, xx + L.r3, yy + L.r1) * T(-3);
+		Dyy = (float)ret;
 		ret = 0;
 		const int b = L.b;
-		ret += block_zero(d, stride, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * 1.0f;
-		ret += block_zero(d, stride, W, H, xx, yy - b - 1, xx + b, yy - 1) * -1.0f;
-		ret += block_zero(d, stride, W, H, xx, yy, xx + b, yy + b) * 1.0f;
-		ret += block_zero(d, stride, W, H, xx - b - 1, yy, xx - 1, yy + b) * -1.0f;
-		Dxy = ret;
+		ret += block_zero<T>(d, stride, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * T(1);
+		ret += block_zero<T>(d, stride, W, H, xx, yy - b - 1, xx + b, yy - 1) * T(-1);
+		ret += block_zero<T>(d, stride, W, H, xx, yy, xx + b, yy + b) * T(1);
+		ret += block_zero<T>(d, stride, W, H, xx - b - 1, yy, xx - 1, yy + b) * T(-1);
+		Dxy = (float)ret;
 	}
 	Dxx *= L.norm;
 	Dxy *= L.norm;
@@ -136,7 +140,7 @@ static HessLevel makeLevel(int size, int skip) {
 }
 
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
-						long long imageStrideOut, int outStride, const HessLevelSource* from) {
+						long long imageStrideOut, int outStride, const HessLevelSource* from, bool intTaps) {
 	if (nlevels > BHIP_MAX_LEVELS) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "too many scales per octave");
 	HessParams P;
 	P.ii = ii;
@@ -158,7 +162,8 @@ int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlev
 		// algorithmic bytes: the integral image once + every level's intensity written once
 		const double bytes = 4.0 * ii.width * ii.height * batch + 4.0 * nlevels * (double)P.w * P.h * batch;
 		ProfScope ps(ctx, skip == 1 ? "k_hessian_skip1" : "k_hessian_skipN", bytes);
-		hipLaunchKernelGGL(k_hessian, grid, dim3(256), 0, ctx->stream, P);
+		if (intTaps) hipLaunchKernelGGL(k_hessian<int>, grid, dim3(256), 0, ctx->stream, P);
+		else hipLaunchKernelGGL(k_hessian<float>, grid, dim3(256), 0, ctx->stream, P);
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

@@ -342,7 +342,9 @@ struct BriefParams {
 	int* out;                 // [n][words]
 };
 
-// one thread = one 32-pair word of one key point
+// one thread = one 32-pair word of one key point.  PIX = float (ImplDescribeBinaryCompare_F32: a pair outside the image is skipped
+// without shifting the word) or unsigned char (ImplDescribeBinaryCompare_U8.java:73-101: the word is shifted for EVERY pair)
+template <class PIX>
 __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 	const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= (long long)P.n * P.words) return;
@@ -356,9 +358,13 @@ __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 		const int ax = P.samplePoints[2 * ia] + c_x, ay = P.samplePoints[2 * ia + 1] + c_y;
 		const int bx = P.samplePoints[2 * ib] + c_x, by = P.samplePoints[2 * ib + 1] + c_y;
 		const bool ok = inside || (ax >= 0 && ax < P.width && ay >= 0 && ay < P.height && bx >= 0 && bx < P.width && by >= 0 && by < P.height);
-		if (ok) {
-			const float va = P.img[(long long)ay * P.stride + ax];
-			const float vb = P.img[(long long)by * P.stride + bx];
+		const PIX* img = (const PIX*)P.img;
+		if (sizeof(PIX) == 1) {
+			desc = desc * 2u;
+			if (ok && img[(long long)ay * P.stride + ax] < img[(long long)by * P.stride + bx]) desc += 1u;
+		} else if (ok) {
+			const PIX va = img[(long long)ay * P.stride + ax];
+			const PIX vb = img[(long long)by * P.stride + bx];
 			desc = desc * 2u + (va < vb ? 1u : 0u);
 		}
 	}
@@ -366,11 +372,12 @@ __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 }
 
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
-					  const int* compare, const double* xy, int n, int* out) {
+					  const int* compare, const double* xy, int n, int* out, bool u8) {
 	if (n <= 0) return BHIP_OK;
 	BriefParams P{img, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out};
 	const long long total = (long long)n * P.words;
-	hipLaunchKernelGGL(k_brief, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, P);
+	if (u8) hipLaunchKernelGGL(k_brief<unsigned char>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, P);
+	else hipLaunchKernelGGL(k_brief<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, P);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
@@ -636,6 +643,52 @@ int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out,
 	ProfScope prof(ctx, "k_median", 8.0 * width * height);
 	hipLaunchKernelGGL(k_median, dim3((width + MED_T - 1) / MED_T, (height + MED_T - 1) / MED_T), dim3(MED_T, MED_T), (size_t)TW * TW * 4, ctx->stream, in, inStride, out,
 					   outStride, width, height, radius);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+
+// ---------------- integral image of an 8-bit image ----------------
+// IntegralImageOps.transform(GrayU8, GrayS32)   I:alg/transform/ii/impl/ImplIntegralImageOps.java:94-118.  Integer sums are exact in any
+// order, so the row pass is a wave-parallel scan (one wave per row, 64 pixels per step with a carry) and the column pass one thread per
+// column.  Bound: HBM (P read as bytes, 4P written, then 8P for the column pass).
+__global__ __launch_bounds__(256) void k_integral_rows_u8(const unsigned char* __restrict__ in, int inStride, int* __restrict__ out, int outStride, int width, int height) {
+	const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (row >= height) return;
+	const unsigned char* r = in + (long long)row * inStride;
+	int* o = out + (long long)row * outStride;
+	int carry = 0;
+	for (int x0 = 0; x0 < width; x0 += 64) {
+		const int x = x0 + lane;
+		int v = x < width ? (int)r[x] : 0;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int t = __shfl_up(v, d, 64);
+			if (lane >= d) v += t;
+		}
+		if (x < width) o[x] = carry + v;
+		carry += __shfl(v, 63, 64);
+	}
+}
+__global__ __launch_bounds__(256) void k_integral_cols_s32(int* __restrict__ io, int stride, int width, int height) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= width) return;
+	int total = 0;
+	for (int y = 0; y < height; y++) {
+		total += io[(long long)y * stride + x];
+		io[(long long)y * stride + x] = total;
+	}
+}
+int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, int inStride, int* out, int outStride, int width, int height) {
+	if (width <= 0 || height <= 0) return BHIP_OK;
+	{
+		ProfScope prof(ctx, "k_integral_rows_u8", 5.0 * width * height);
+		hipLaunchKernelGGL(k_integral_rows_u8, dim3((height + 3) / 4), dim3(256), 0, ctx->stream, in, inStride, out, outStride, width, height);
+	}
+	{
+		ProfScope prof(ctx, "k_integral_cols_s32", 8.0 * width * height);
+		hipLaunchKernelGGL(k_integral_cols_s32, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, out, outStride, width, height);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

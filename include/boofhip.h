@@ -253,6 +253,17 @@ int bhip_pyramid_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, co
  * (F:alg/feature/detect/interest/GeneralFeatureDetector.java:118-160). */
 int bhip_corner_intensity_f32(bhip_ctx* ctx, int kind, int radius, float kappa, const float* derivX, const float* derivY, int dStart, int dStride,
 							  int width, int height, float* intensity, int iStart, int iStride);
+/* Integer image variants at stage level.
+ * bhip_integral_u8_s32: IntegralImageOps.transform(GrayU8, GrayS32) (I:alg/transform/ii/impl/ImplIntegralImageOps.java:94-118).
+ * bhip_hessian_s32: IntegralImageFeatureIntensity.hessian(GrayS32, skip, size, GrayF32) (F:alg/feature/detect/intensity/impl/
+ *   ImplIntegralImageFeatureIntensity.java:245-390): integer box sums, converted to float where the Java code assigns them to a float.
+ * bhip_brief_u8: DescribePointBrief on GrayU8 = ImplDescribeBinaryCompare_U8 (F:alg/feature/describe/impl/ImplDescribeBinaryCompare_U8.java:47-101;
+ *   its border form shifts the word for every pair, the F32 class only for pairs inside the image). */
+int bhip_integral_u8_s32(bhip_ctx* ctx, const uint8_t* in, int inStart, int inStride, int width, int height, int32_t* out, int outStart, int outStride);
+int bhip_hessian_s32(bhip_ctx* ctx, const int32_t* ii, int iiStart, int iiStride, int width, int height, int skip, int size, float* out, int outStart,
+					 int outStride);
+int bhip_brief_u8(bhip_ctx* ctx, const uint8_t* img, int start, int stride, int width, int height, int radius, int numPoints,
+				  const int32_t* samplePoints, const int32_t* compare, const double* xy, int n, int32_t* out);
 /* DescribePointBrief.process for n points on one image (F:alg/feature/describe/DescribePointBrief.java:73-89;
  * F:alg/feature/describe/impl/ImplDescribeBinaryCompare_F32.java:47-101).  The definition (samplePoints[numPoints][2], compare[numPoints][2])
  * is supplied by the caller: FactoryBriefDefinition.gaussian2 depends on java.util.Random + StrictMath and is generated on the Java side. */

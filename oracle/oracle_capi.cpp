@@ -3,6 +3,7 @@
 // cpu_baseline leg.  The product (boofcv_amd/) never links or loads this library.
 #include "boof_oracle.hpp"
 #include "boof_oracle_ip.hpp"
+#include "boof_oracle_int.hpp"
 #include <omp.h>
 
 using namespace oracle;
@@ -357,6 +358,23 @@ int orc_blur_mean(const orc_image* in, const orc_image* out, int radiusX, int ra
 int orc_blur_median(const orc_image* in, const orc_image* out, int radius) {
 	try { GrayF32 o = view(out); blurMedian(view(in), o, radius); } catch (const std::exception&) { return -1; }
 	return 0;
+}
+// ---- integer image variants, stage level ----
+void orc_integral_u8(const uint8_t* in, int inStart, int inStride, int w, int h, int32_t* out, int outStart, int outStride) {
+	GrayU8v i{in, inStart, inStride, w, h};
+	GrayS32v o{out, outStart, outStride, w, h};
+	integral_transform_u8(i, o);
+}
+void orc_hessian_s32(const int32_t* ii, int iiStart, int iiStride, int w, int h, int skip, int size, const orc_image* out) {
+	GrayS32v v{(int32_t*)ii, iiStart, iiStride, w, h};
+	GrayF32 o = view(out);
+	hessian_s32(v, skip, size, o);
+}
+void orc_brief_u8(const uint8_t* img, int start, int stride, int w, int h, int radius, int numPoints, const int* samplePoints, const int* compare, const double* xy,
+				  int n, int32_t* out) {
+	GrayU8v v{img, start, stride, w, h};
+	const int words = (numPoints + 31) / 32;
+	for (int i = 0; i < n; i++) brief_u8(v, radius, numPoints, samplePoints, compare, (int)xy[2 * i], (int)xy[2 * i + 1], out + (size_t)i * words);
 }
 void orc_subsample(const orc_image* in, const orc_image* out, int skip) { GrayF32 o = view(out); pyramidSubsample(view(in), o, skip); }
 

@@ -122,6 +122,9 @@ def lib():
             "orc_conv2d": (None, [P(C.c_float), C.c_int, C.c_int, IM, IM]),
             "orc_blur_mean": (C.c_int, [IM, IM, C.c_int, C.c_int, IM]),
             "orc_blur_median": (C.c_int, [IM, IM, C.c_int]),
+            "orc_integral_u8": (None, [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int32), C.c_int, C.c_int]),
+            "orc_hessian_s32": (None, [P(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, IM]),
+            "orc_brief_u8": (None, [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_double), C.c_int, P(C.c_int32)]),
             "orc_ssd_corner": (C.c_int, [IM, IM, C.c_int, C.c_int, C.c_float, P(C.c_float)]),
             "orc_conv_down_norm": (C.c_int, [C.c_int, P(C.c_float), C.c_int, IM, IM, C.c_int]),
             "orc_down_max_side": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -412,6 +415,35 @@ def blur_median(src, radius):
     out = Gray(src.width, src.height)
     if lib().orc_blur_median(src.c(), out.c(), radius) != 0:
         raise ValueError("Radius must be > 0")
+    return out
+
+
+def integral_u8(img_u8):
+    """IntegralImageOps.transform(GrayU8, GrayS32): (H, W) uint8 -> (H, W) int32."""
+    a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = a.shape
+    out = np.zeros((h, w), dtype=np.int32)
+    lib().orc_integral_u8(_fp(a, C.c_uint8), 0, w, w, h, _fp(out, C.c_int32), 0, w)
+    return out
+
+
+def hessian_s32(ii_s32, skip, size):
+    """IntegralImageFeatureIntensity.hessian(GrayS32, skip, size, intensity) -> (H/skip, W/skip) float32."""
+    a = np.ascontiguousarray(ii_s32, dtype=np.int32)
+    h, w = a.shape
+    out = Gray(w // skip, h // skip)
+    lib().orc_hessian_s32(_fp(a, C.c_int32), 0, w, w, h, skip, size, out.c())
+    return out.array().copy()
+
+
+def brief_describe_u8(img_u8, xy, radius, samplePoints, compare):
+    a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = a.shape
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    sp = np.ascontiguousarray(samplePoints, dtype=np.int32); cp = np.ascontiguousarray(compare, dtype=np.int32)
+    n = len(cp)
+    out = np.zeros((len(xy), (n + 31) // 32), dtype=np.int32)
+    lib().orc_brief_u8(_fp(a, C.c_uint8), 0, w, w, h, radius, n, _fp(sp, C.c_int), _fp(cp, C.c_int), _fp(xy, C.c_double), len(xy), _fp(out, C.c_int32))
     return out
 
 

@@ -767,6 +767,37 @@ def test_corner_intensity_and_general_detector(api, orc, w, h):
         api.FactoryIntensityPointAlg.shiTomasi(5, False, api.GrayF32).process(api.GrayF32(6, 6), api.GrayF32(6, 6), api.GrayF32(1, 1))
 
 
+def test_integer_variants_stage_level(api, orc):
+    """SURVEY 8f-4 at stage level: GrayU8 -> GrayS32 integral image (exact), Hessian intensity from the S32 integral image (bit-exact),
+    BRIEF-512 on GrayU8 (inside and border forms)."""
+    rng = np.random.default_rng(12)
+    for (w, h) in [(60, 70), (640, 480), (1920, 1080), (1, 1), (65, 3), (130, 200)]:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        ii = api.IntegralImageOps.transform(api.GrayU8.wrap(img))
+        assert isinstance(ii, api.GrayS32) and np.array_equal(ii.array(), orc.integral_u8(img))
+        if w >= 60 and h >= 70:
+            for skip, size in [(1, 9), (1, 27), (2, 15), (2, 51), (4, 27), (3, 9)]:
+                if size > min(w, h):
+                    continue
+                inten = api.GrayF32(w // skip, h // skip)
+                api.IntegralImageFeatureIntensity.hessian(ii, skip, size, inten)
+                assert np.array_equal(bits(inten.array()), bits(orc.hessian_s32(ii.array(), skip, size))), (w, h, skip, size)
+    # sub-image views
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    big = np.zeros((60, 80), np.uint8); big[5:53, 7:71] = img
+    sub = api.GrayU8(64, 48, big.reshape(-1), 5 * 80 + 7, 80)
+    out = api.GrayS32(70, 50).subimage(3, 1, 67, 49)
+    api.IntegralImageOps.transform(sub, out)
+    assert np.array_equal(out.array(), orc.integral_u8(img))
+    # BRIEF on GrayU8
+    sp, cp = orc.brief_definition()
+    img = rng.integers(0, 256, (120, 160), dtype=np.uint8)
+    xy = np.concatenate([rng.uniform(0, 160, (200, 1)), rng.uniform(0, 120, (200, 1))], axis=1)
+    xy = np.concatenate([xy, [[0, 0], [159.9, 119.9], [16, 16], [15.9, 50], [143, 103], [144, 104]]])
+    b = api.DescribePointBrief(16, sp, cp); b.setImage(api.GrayU8.wrap(img))
+    assert np.array_equal(b.processAll(xy), orc.brief_describe_u8(img, xy, 16, sp, cp))
+
+
 def test_associate_surf_basic(api, orc):
     """AssociateSurfBasic / WrapAssociateSurfBasic (TestAssociateSurfBasic.java literals + detected SURF features of two noise images)."""
     def feats(desc, white):

@@ -665,3 +665,50 @@ def test_blur_mean_median_and_conv2d(orc):
             for x in range(oL, w - oR):
                 assert abs(got[y, x] - (a[y - oL:y - oL + kw, x - oL:x - oL + kw] * k).sum()) < 1e-3
         assert got[0, 0] == -7 and got[-1, -1] == -7
+
+
+# ---------------------------------------------------------------------------------------------------
+# Integer image variants, stage level
+# ---------------------------------------------------------------------------------------------------
+def test_integer_variants_stage_level(orc):
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (70, 60), dtype=np.uint8)
+    # IT:alg/transform/ii/impl/TestImplIntegralImageOps.java (GrayU8 -> GrayS32): ii(x, y) = sum of the pixels above and to the left, exactly
+    ii = orc.integral_u8(img)
+    assert np.array_equal(ii, img.astype(np.int64).cumsum(0).cumsum(1).astype(np.int32))
+    # Hessian on the S32 integral: all-int box sums -> identical to a brute-force evaluation of computeHessian in exact arithmetic
+    # (FT:alg/feature/detect/intensity/impl/TestImplIntegralImageFeatureIntensity.java:44-69 compares inner + border with naive, 1e-4)
+    def block(x0, y0, x1, y1):
+        h, w = ii.shape
+        x0, y0, x1, y1 = min(x0, w - 1), min(y0, h - 1), min(x1, w - 1), min(y1, h - 1)
+        g = lambda x, y: int(ii[y, x]) if x >= 0 and y >= 0 else 0
+        return g(x1, y1) - g(x1, y0) - g(x0, y1) + g(x0, y0)
+    for skip, size in [(1, 9), (2, 15), (3, 9)]:
+        got = orc.hessian_s32(ii, skip, size)
+        bw = size // 3; bh = size - bw - 1; r1 = bw // 2; r2 = bw + r1; r3 = bh // 2
+        norm = np.float32(1.0) / np.float32(size * size)
+        for (x, y) in [(0, 0), (5, 7), (got.shape[1] - 1, got.shape[0] - 1), (got.shape[1] // 2, got.shape[0] // 2), (1, got.shape[0] // 2)]:
+            xx, yy = x * skip, y * skip
+            dxx = block(xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) - 3 * block(xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3)
+            dyy = block(xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) - 3 * block(xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1)
+            dxy = (block(xx - bw - 1, yy - bw - 1, xx - 1, yy - 1) - block(xx, yy - bw - 1, xx + bw, yy - 1) + block(xx, yy, xx + bw, yy + bw)
+                   - block(xx - bw - 1, yy, xx - 1, yy + bw))
+            Dxx, Dyy, Dxy = np.float32(dxx) * norm, np.float32(dyy) * norm, np.float32(dxy) * norm
+            exp = np.float32(np.float32(Dxx * Dyy) - np.float32(np.float32(np.float32(0.81) * Dxy) * Dxy))
+            assert got[y, x] == exp, (skip, size, x, y)
+    # BRIEF on GrayU8 (FT:alg/feature/describe/BaseTestDescribePointBinaryCompare.java:141-191): bit order, and border == inside when inside
+    sp, cp = orc.brief_definition()
+    inside = orc.brief_describe_u8(img, [[30, 35]], 16, sp, cp)[0]
+    vals = lambda k: (int(img[35 + sp[cp[k, 0], 1], 30 + sp[cp[k, 0], 0]]), int(img[35 + sp[cp[k, 1], 1], 30 + sp[cp[k, 1], 0]]))
+    for k in (0, 1, 31, 32, 500, 511):
+        a, b = vals(k)
+        assert ((int(inside[k // 32]) >> (31 - k % 32)) & 1) == (1 if a < b else 0)
+    big = np.zeros((100, 100), np.uint8); big[10:80, 20:80] = img
+    assert np.array_equal(orc.brief_describe_u8(big, [[50, 45]], 16, sp, cp)[0], inside)
+    # border form: the word is shifted for every pair (unlike the F32 class), so out-of-image pairs leave 0 bits in place
+    edge = orc.brief_describe_u8(img, [[3, 3]], 16, sp, cp)[0]
+    for k in range(64):
+        ax, ay = 3 + sp[cp[k, 0], 0], 3 + sp[cp[k, 0], 1]; bx, by = 3 + sp[cp[k, 1], 0], 3 + sp[cp[k, 1], 1]
+        ok = 0 <= ax < 60 and 0 <= ay < 70 and 0 <= bx < 60 and 0 <= by < 70
+        bit = (int(edge[k // 32]) >> (31 - k % 32)) & 1
+        assert bit == (1 if ok and img[ay, ax] < img[by, bx] else 0)
