@@ -94,6 +94,7 @@ SIGNATURES = {
     "bhip_corner_intensity_f32": (_i, [_vp, _i, _i, _f, _fp, _fp, _i, _i, _i, _i, _fp, _i, _i]),
     "bhip_integral_u8_s32": (_i, [_vp, _u8p, _i, _i, _i, _i, _i32p, _i, _i]),
     "bhip_hessian_s32": (_i, [_vp, _i32p, _i, _i, _i, _i, _i, _i, _fp, _i, _i]),
+    "bhip_fh_detect_s32": (_i, [_vp, P(FhCfg), _i32p, _i, _i, _i, _i, _dp, _i, _ip]),
     "bhip_brief_u8": (_i, [_vp, _u8p, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _dp, _i, _i32p]),
     "bhip_brief_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _dp, _i, _i32p]),
 }

@@ -980,7 +980,8 @@ class FastHessianFeatureDetector:
         while True:
             out = np.zeros((cap, 3))
             n = C.c_int(0)
-            _check(self.ctx, _lib.load().bhip_fh_detect_f32(self.ctx._h, C.byref(cfg), integral._p(), integral.startIndex, integral.stride, integral.width,
+            fn = _lib.load().bhip_fh_detect_s32 if isinstance(integral, GrayS32) else _lib.load().bhip_fh_detect_f32
+            _check(self.ctx, fn(self.ctx._h, C.byref(cfg), integral._p(), integral.startIndex, integral.stride, integral.width,
                                                            integral.height, out.ctypes.data_as(_lib._dp), cap, C.byref(n)))
             if n.value <= cap:
                 self.foundPoints = out[:n.value].copy()

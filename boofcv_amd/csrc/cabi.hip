@@ -40,7 +40,7 @@ bool bhip_fused_plan(int skip, int nlevels, const int* sizes, int radius, int* T
 bool bhip_fused_is_fixed(int skip, int nlevels, const int* sizes, int radius);
 int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, int nmid, const DetectLevelParams* mids,
 							 const int* midLevels, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							 int cap, const FusedExport* exp);
+							 int cap, const FusedExport* exp, bool intTaps = false);
 
 // per-context scratch that the stateless entry points reuse
 struct CtxScratch {
@@ -153,6 +153,7 @@ struct FhOctavePlan {
 struct FhDetector {
 	bhip_fh_cfg cfg;
 	int W = 0, H = 0, batch = 0, cap = 0;
+	bool intTaps = false;   // the integral image holds int32 (GrayS32, from a GrayU8 frame) instead of float
 	std::vector<FhOctavePlan> plan;
 	int bitmapWords = 0;
 	DevBuf inten, expBuf, bitmap, prefix, cand, sorted, count;
@@ -221,6 +222,7 @@ struct FhDetector {
 			int ftx, fty, flds;
 			o.fused = !unfusedOnly() && !o.mids.empty() && bhip_fused_plan(o.skip, o.nlevels, o.sizes, cfg.extractRadius, &ftx, &fty, &flds);
 			o.fixed = o.fused && bhip_fused_is_fixed(o.skip, o.nlevels, o.sizes, cfg.extractRadius);
+			if (intTaps && !o.fixed) o.fused = false;   // integer taps: compile-time-geometry fused kernel or the stand-alone kernels
 			o.nexport = 0;
 			for (int i = 0; i < BHIP_MAX_LEVELS; i++) { o.shareFrom[i] = -1; o.exportSlot[i] = -1; }
 		}
@@ -299,7 +301,7 @@ struct FhDetector {
 					}
 					BHIP_TRY(bhip_launch_detect_fused(ctx, ii, batch, o.skip, o.nlevels, o.sizes, (int)o.mids.size(), mp, ml, cfg.extractRadius,
 													  cfg.detectThreshold, bitmap.as<unsigned int>(), bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap,
-													  ex.n > 0 ? &ex : nullptr));
+													  ex.n > 0 ? &ex : nullptr, intTaps));
 					continue;
 				}
 				const long long levelStride = (long long)o.w * o.h;
@@ -314,7 +316,7 @@ struct FhDetector {
 					if (p.fused) from[i] = HessLevelSource{expBuf.as<float>() + p.expOff + (size_t)p.exportSlot[j] * levelStride, p.expImageStride, o.w, 1};
 					else from[i] = HessLevelSource{inten.as<float>() + p.intenOff + (size_t)j * p.w * p.h, p.intenImageStride, p.w, 2};
 				}
-				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, base, levelStride, imageStride, o.w, from));
+				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, base, levelStride, imageStride, o.w, from, intTaps));
 				for (auto& m : o.mids) {
 					BHIP_TRY(bhip_launch_nms_scalespace(ctx, base + (m.level - 1) * levelStride, base + m.level * levelStride, base + (m.level + 1) * levelStride,
 														imageStride, o.w, batch, m.p, cfg.extractRadius, cfg.detectThreshold, bitmap.as<unsigned int>(),
@@ -732,6 +734,37 @@ int bhip_fh_detect_f32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const float* ii, i
 	if (cfg) det.cfg = *cfg; else bhip_fh_cfg_default(&det.cfg);
 	CtxScratch* sc = scratchOf(ctx);
 	int status = uploadImage(ctx, sc->a, ii, iiStart, iiStride, width, height);
+	if (status == BHIP_OK) status = det.prepare(ctx, width, height, 1);
+	ImgView iv{sc->a.as<float>(), (long long)width * height, width, width, height};
+	if (status == BHIP_OK) status = det.run(ctx, iv);
+	if (status == BHIP_OK) {
+		*n = det.counts[0];
+		const int ncopy = std::min(*n, cap);
+		if (ncopy > 0) {
+			std::vector<KeyPoint> kps(ncopy);
+			hipError_t e = hipMemcpyAsync(kps.data(), det.sorted.p, (size_t)ncopy * sizeof(KeyPoint), hipMemcpyDeviceToHost, ctx->stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+			if (e != hipSuccess) status = bhip_fail(ctx, BHIP_ERR_HIP, hipGetErrorString(e));
+			else for (int i = 0; i < ncopy; i++) { xy_scale[3 * i] = kps[i].x; xy_scale[3 * i + 1] = kps[i].y; xy_scale[3 * i + 2] = kps[i].scale; }
+		}
+	}
+	(void)hipStreamSynchronize(ctx->stream);
+	det.release();
+	return status;
+}
+
+// FastHessianFeatureDetector<GrayS32>.detect(integral) (the integral image of a GrayU8 frame)
+int bhip_fh_detect_s32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const int32_t* ii, int iiStart, int iiStride, int width, int height, double* xy_scale,
+					   int cap, int* n) {
+	CHECK_CTX(ctx);
+	if (!ii || width <= 0 || height <= 0 || iiStride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image");
+	if (!n || cap < 0 || (cap > 0 && !xy_scale)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad output");
+	*n = 0;
+	FhDetector det;
+	det.intTaps = true;
+	if (cfg) det.cfg = *cfg; else bhip_fh_cfg_default(&det.cfg);
+	CtxScratch* sc = scratchOf(ctx);
+	int status = uploadImage(ctx, sc->a, (const float*)ii, iiStart, iiStride, width, height);   // 32-bit words either way
 	if (status == BHIP_OK) status = det.prepare(ctx, width, height, 1);
 	ImgView iv{sc->a.as<float>(), (long long)width * height, width, width, height};
 	if (status == BHIP_OK) status = det.run(ctx, iv);

@@ -273,42 +273,48 @@ struct FixedGeo {
 };
 
 // block_zero on the phase-plane patch (see lblock_zero)
-template <class G>
-__device__ __forceinline__ float pblock_zero(const float* iiT, int X0, int Y0, int W, int H, int x0, int y0, int x1, int y1) {
+// T = float (GrayF32 integral image) or int (GrayS32: the box sums are exact integers and become floats exactly where the reference's S32
+// code assigns them to a float, ImplIntegralImageFeatureIntensity.java:245-390)
+template <class T> struct TapVec2;
+template <> struct TapVec2<float> { typedef float2 type; };
+template <> struct TapVec2<int> { typedef int2 type; };
+
+template <class G, class T>
+__device__ __forceinline__ T pblock_zero(const T* iiT, int X0, int Y0, int W, int H, int x0, int y0, int x1, int y1) {
 	x0 = min(x0, W - 1); y0 = min(y0, H - 1); x1 = min(x1, W - 1); y1 = min(y1, H - 1);
 	const int cx0 = max(x0, 0) - X0, cy0 = max(y0, 0) - Y0, cx1 = max(x1, 0) - X0, cy1 = max(y1, 0) - Y0;
-	const float vbr = iiT[G::at(cy1, cx1)], vtr = iiT[G::at(cy0, cx1)], vbl = iiT[G::at(cy1, cx0)], vtl = iiT[G::at(cy0, cx0)];
-	const float br = (x1 >= 0 && y1 >= 0) ? vbr : 0.0f;
-	const float tr = (y0 >= 0 && x1 >= 0) ? vtr : 0.0f;
-	const float bl = (x0 >= 0 && y1 >= 0) ? vbl : 0.0f;
-	const float tl = (x0 >= 0 && y0 >= 0) ? vtl : 0.0f;
+	const T vbr = iiT[G::at(cy1, cx1)], vtr = iiT[G::at(cy0, cx1)], vbl = iiT[G::at(cy1, cx0)], vtl = iiT[G::at(cy0, cx0)];
+	const T br = (x1 >= 0 && y1 >= 0) ? vbr : T(0);
+	const T tr = (y0 >= 0 && x1 >= 0) ? vtr : T(0);
+	const T bl = (x0 >= 0 && y1 >= 0) ? vbl : T(0);
+	const T tl = (x0 >= 0 && y0 >= 0) ? vtl : T(0);
 	return br - tr - bl + tl;
 }
 
 // the 32 taps of one inner pixel, reference order (hessianInner :183-201); c = patch row of yy, column slot of x
-template <class G, int L>
-__device__ __forceinline__ float fusedInnerDet(const float* c) {
+template <class G, int L, class T>
+__device__ __forceinline__ float fusedInnerDet(const T* c) {
 	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), rF = G::rF(L), rS = G::rS(L);
 	constexpr float norm = 1.0f / (float)(size * size);
 #define TAP(ro, co) c[G::tap((ro), (co))]
 	float Dxx, Dyy, Dxy;
 	{
 		constexpr int rt = -rS - 1, rb = rt + bLg, c0 = -rF - 1;
-		Dxx = TAP(rb, c0 + 3 * bS) - TAP(rt, c0 + 3 * bS) - TAP(rb, c0) + TAP(rt, c0);
-		Dxx -= 3 * (TAP(rb, c0 + 2 * bS) - TAP(rt, c0 + 2 * bS) - TAP(rb, c0 + bS) + TAP(rt, c0 + bS));
+		Dxx = (float)(TAP(rb, c0 + 3 * bS) - TAP(rt, c0 + 3 * bS) - TAP(rb, c0) + TAP(rt, c0));
+		Dxx -= (float)(T(3) * (TAP(rb, c0 + 2 * bS) - TAP(rt, c0 + 2 * bS) - TAP(rb, c0 + bS) + TAP(rt, c0 + bS)));
 	}
 	{
 		constexpr int r0 = -rF - 1, cl = -rS - 1, cr = cl + bLg;
-		Dyy = TAP(r0 + 3 * bS, cr) - TAP(r0 + 3 * bS, cl) - TAP(r0, cr) + TAP(r0, cl);
-		Dyy -= 3 * (TAP(r0 + 2 * bS, cr) - TAP(r0 + 2 * bS, cl) - TAP(r0 + bS, cr) + TAP(r0 + bS, cl));
+		Dyy = (float)(TAP(r0 + 3 * bS, cr) - TAP(r0 + 3 * bS, cl) - TAP(r0, cr) + TAP(r0, cl));
+		Dyy -= (float)(T(3) * (TAP(r0 + 2 * bS, cr) - TAP(r0 + 2 * bS, cl) - TAP(r0 + bS, cr) + TAP(r0 + bS, cl)));
 	}
 	{
 		constexpr int ry1 = -bS - 1, ry2 = ry1 + bS, ry3 = ry2 + 1, ry4 = ry3 + bS, c0 = -bS - 1;
 		constexpr int x3 = bS + 1, x4 = x3 + bS;
-		Dxy = TAP(ry2, c0 + bS) - TAP(ry1, c0 + bS) - TAP(ry2, c0) + TAP(ry1, c0);
-		Dxy -= TAP(ry2, c0 + x4) - TAP(ry1, c0 + x4) - TAP(ry2, c0 + x3) + TAP(ry1, c0 + x3);
-		Dxy += TAP(ry4, c0 + x4) - TAP(ry3, c0 + x4) - TAP(ry4, c0 + x3) + TAP(ry3, c0 + x3);
-		Dxy -= TAP(ry4, c0 + bS) - TAP(ry3, c0 + bS) - TAP(ry4, c0) + TAP(ry3, c0);
+		Dxy = (float)(TAP(ry2, c0 + bS) - TAP(ry1, c0 + bS) - TAP(ry2, c0) + TAP(ry1, c0));
+		Dxy -= (float)(TAP(ry2, c0 + x4) - TAP(ry1, c0 + x4) - TAP(ry2, c0 + x3) + TAP(ry1, c0 + x3));
+		Dxy += (float)(TAP(ry4, c0 + x4) - TAP(ry3, c0 + x4) - TAP(ry4, c0 + x3) + TAP(ry3, c0 + x3));
+		Dxy -= (float)(TAP(ry4, c0 + bS) - TAP(ry3, c0 + bS) - TAP(ry4, c0) + TAP(ry3, c0));
 	}
 #undef TAP
 	Dxx *= norm;
@@ -317,8 +323,8 @@ __device__ __forceinline__ float fusedInnerDet(const float* c) {
 	return Dxx * Dyy - 0.81f * Dxy * Dxy;
 }
 
-template <class G, int SKIP, int NL, int R, int L>
-__device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const float* iiT, float* inten, int tid, int x0, int y0, int X0, int Y0) {
+template <class G, int SKIP, int NL, int R, int L, class T>
+__device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const T* iiT, float* inten, int tid, int x0, int y0, int X0, int Y0) {
 	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), border = G::border(L);
 	constexpr float norm = 1.0f / (float)(size * size);
 	constexpr int pitch = G::IWp;
@@ -332,8 +338,8 @@ __device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const floa
 #pragma unroll 2
 		for (int it = tid; it < G::ITH * G::ITW; it += 256) {
 			const int px = it & (G::ITW - 1), py = it / G::ITW;
-			const float* c = iiT + (rowBase + py * SKIP) * pitch + px;
-			out[py * G::ITp + px] = fusedInnerDet<G, L>(c);
+			const T* c = iiT + (rowBase + py * SKIP) * pitch + px;
+			out[py * G::ITp + px] = fusedInnerDet<G, L, T>(c);
 		}
 	} else {
 #pragma unroll 1
@@ -347,23 +353,23 @@ __device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const floa
 				const int xx = x * SKIP, yy = y * SKIP;
 				const bool inner = x >= border && x < P.w - border && y >= border && y < P.h - border;
 				if (inner) {
-					det = fusedInnerDet<G, L>(iiT + (yy - Y0) * pitch + (x - x0 + R));
+					det = fusedInnerDet<G, L, T>(iiT + (yy - Y0) * pitch + (x - x0 + R));
 				} else {
 					float Dxx, Dyy, Dxy;
-					float ret = 0;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * 1.0f;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * -3.0f;
-					Dxx = ret;
+					T ret = 0;
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * T(1);
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * T(-3);
+					Dxx = (float)ret;
 					ret = 0;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * 1.0f;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * -3.0f;
-					Dyy = ret;
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * T(1);
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * T(-3);
+					Dyy = (float)ret;
 					ret = 0;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * 1.0f;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * -1.0f;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * 1.0f;
-					ret += pblock_zero<G>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * -1.0f;
-					Dxy = ret;
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * T(1);
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * T(-1);
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * T(1);
+					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * T(-1);
+					Dxy = (float)ret;
 					Dxx *= norm;
 					Dxy *= norm;
 					Dyy *= norm;
@@ -373,14 +379,14 @@ __device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const floa
 			out[py * G::ITp + px] = det;
 		}
 	}
-	if constexpr (L + 1 < NL) fusedLevelFixed<G, SKIP, NL, R, L + 1>(P, iiT, inten, tid, x0, y0, X0, Y0);
+	if constexpr (L + 1 < NL) fusedLevelFixed<G, SKIP, NL, R, L + 1, T>(P, iiT, inten, tid, x0, y0, X0, Y0);
 }
 
-template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
+template <class T, int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
 __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	typedef FixedGeo<SKIP, SIZE0, STEPSZ, NL, R, ITWT, TYT> G;
 	extern __shared__ __attribute__((aligned(16))) float fl[];
-	float* iiT = fl;
+	T* iiT = (T*)fl;   // 32-bit words either way
 	float* inten = fl + SKIP * G::plane;
 	const int tid = threadIdx.x;
 	// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one L2), so block b takes
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		bx = rem - by * tilesX;
 	}
 	const int x0 = bx * G::TX, y0 = by * G::TY;
-	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
+	const T* __restrict__ d = (const T*)P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const int X0 = (x0 - R) * SKIP - G::rFmax - 1, Y0 = (y0 - R) * SKIP - G::rFmax - 1;
 	bool staged = false;
@@ -413,16 +419,17 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			static_assert(PAIRS <= 64, "one lane per float2 of a patch row");
 			constexpr int RB = (G::IH + 7) / 8;
 			for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
-				float2 v[RB];
+				typedef typename TapVec2<T>::type T2;
+				T2 v[RB];
 #pragma unroll
 				for (int k = 0; k < RB; k++) {
 					const int ry = ry0 + 4 * k;
 					const int gy = Y0 + ry;
 					const int gx = X0 + 2 * tx;
 					const bool ok = ry < G::IH && gy >= 0 && gy < H && tx < PAIRS && gx >= 0 && gx < W;
-					const float2* __restrict__ src = (const float2*)(d + (long long)(ok ? gy : 0) * stride + (ok ? gx : 0));
+					const T2* __restrict__ src = (const T2*)(d + (long long)(ok ? gy : 0) * stride + (ok ? gx : 0));
 					v[k] = *src;
-					if (!ok) v[k] = make_float2(0.0f, 0.0f);
+					if (!ok) { v[k].x = T(0); v[k].y = T(0); }
 				}
 #pragma unroll
 				for (int k = 0; k < RB; k++) {
@@ -442,20 +449,20 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		constexpr int COLS = (G::IW + 63) / 64;   // 64-float column chunks per row
 		constexpr int RB = (G::IH + 7) / 8;       // rows per batch: the whole patch in two batches of independent loads
 		for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
-			float v[RB][COLS];
+			T v[RB][COLS];
 #pragma unroll
 			for (int k = 0; k < RB; k++) {
 				const int ry = ry0 + 4 * k;
 				const int gy = Y0 + ry;
 				const bool rowOk = ry < G::IH && gy >= 0 && gy < H;
-				const float* __restrict__ src = d + (long long)(rowOk ? gy : 0) * stride;
+				const T* __restrict__ src = d + (long long)(rowOk ? gy : 0) * stride;
 #pragma unroll
 				for (int cc = 0; cc < COLS; cc++) {
 					const int rx = cc * 64 + tx;
 					const int gx = X0 + rx;
 					const bool ok = rowOk && rx < G::IW && gx >= 0 && gx < W;
 					v[k][cc] = src[ok ? gx : 0];
-					if (!ok) v[k][cc] = 0.0f;
+					if (!ok) v[k][cc] = T(0);
 				}
 			}
 #pragma unroll
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		}
 	}
 	__syncthreads();
-	if (!(P.ablate & 1)) fusedLevelFixed<G, SKIP, NL, R, 0>(P, iiT, inten, tid, x0, y0, X0, Y0);
+	if (!(P.ablate & 1)) fusedLevelFixed<G, SKIP, NL, R, 0, T>(P, iiT, inten, tid, x0, y0, X0, Y0);
 	__syncthreads();
 	if (P.nexp > 0) {
 		// even pixels of the tile core -> pixel (x/2, y/2) of the next octave
@@ -592,7 +599,7 @@ bool bhip_fused_is_fixed(int skip, int nlevels, const int* sizes, int radius) {
 
 int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, int nmid, const DetectLevelParams* mids,
 							 const int* midLevels, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							 int cap, const FusedExport* exp) {
+							 int cap, const FusedExport* exp, bool intTaps) {
 	FusedParams P;
 	int TX, TY, lds;
 	if (!bhip_fused_plan(skip, nlevels, sizes, radius, &TX, &TY, &lds)) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "octave does not fit the fused tile");
@@ -644,7 +651,8 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV> G;                                                                               \
 		const long long nt = (long long)((P.w + G::TX - 1) / G::TX) * ((P.h + G::TY - 1) / G::TY) * batch;                              \
 		dim3 g((unsigned)(((nt + 7) >> 3) << 3));                                                                                      \
-		hipLaunchKernelGGL((k_detect_fused_fixed<SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
+		if (intTaps) hipLaunchKernelGGL((k_detect_fused_fixed<int, SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
+		else hipLaunchKernelGGL((k_detect_fused_fixed<float, SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
 		launched = true;                                                                                                               \
 	} while (0)
 			if (arith && skip == 1 && sizes[0] == 9 && step == 6) {
@@ -659,6 +667,7 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 #undef LAUNCH_FIXED
 		}
 		if (!launched) {
+			if (intTaps) return bhip_fail(ctx, BHIP_ERR_INVALID, "integer taps need the fixed-geometry fused kernel");
 			if (P.nexp > 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "level export needs the fixed-geometry fused kernel");
 			hipLaunchKernelGGL(k_detect_fused, grid, dim3(256), (size_t)lds, ctx->stream, P);
 		}

@@ -262,6 +262,10 @@ int bhip_corner_intensity_f32(bhip_ctx* ctx, int kind, int radius, float kappa, 
 int bhip_integral_u8_s32(bhip_ctx* ctx, const uint8_t* in, int inStart, int inStride, int width, int height, int32_t* out, int outStart, int outStride);
 int bhip_hessian_s32(bhip_ctx* ctx, const int32_t* ii, int iiStart, int iiStride, int width, int height, int skip, int size, float* out, int outStart,
 					 int outStride);
+/* FastHessianFeatureDetector<GrayS32>.detect(integral) (F:alg/feature/detect/interest/FastHessianFeatureDetector.java:156-188 on the integral image
+ * of a GrayU8 frame): same outputs as bhip_fh_detect_f32 */
+int bhip_fh_detect_s32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const int32_t* ii, int iiStart, int iiStride, int width, int height,
+					   double* xy_scale, int cap, int* n);
 int bhip_brief_u8(bhip_ctx* ctx, const uint8_t* img, int start, int stride, int width, int height, int radius, int numPoints,
 				  const int32_t* samplePoints, const int32_t* compare, const double* xy, int n, int32_t* out);
 /* DescribePointBrief.process for n points on one image (F:alg/feature/describe/DescribePointBrief.java:73-89;

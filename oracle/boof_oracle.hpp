@@ -457,8 +457,9 @@ struct FastHessianFeatureDetector {
 		extractor.border = 0;
 	}
 
-	// :156-188 detect
-	void detect(const GrayF32& integral) {
+	// :156-188 detect (II = GrayF32, or the GrayS32 view of boof_oracle_int.hpp: only hessian() touches the pixels)
+	template <class II>
+	void detect(const II& integral) {
 		if (intensity[0].storage.size() < (size_t)integral.width * integral.height)
 			for (int i = 0; i < 3; i++) intensity[i].reshape(integral.width, integral.height);
 		foundPoints.clear();
@@ -477,7 +478,8 @@ struct FastHessianFeatureDetector {
 		}
 	}
 	// :198-221 detectOctave
-	void detectOctave(const GrayF32& integral, int skip, const std::vector<int>& featureSize, int octave) {
+	template <class II>
+	void detectOctave(const II& integral, int skip, const std::vector<int>& featureSize, int octave) {
 		int w = integral.width / skip, h = integral.height / skip;
 		for (int i = 0; i < 3; i++) intensity[i].reshape(w, h);
 		for (size_t i = 0; i < featureSize.size(); i++) {

@@ -106,6 +106,9 @@ inline void hessian_s32(const GrayS32v& ii, int skip, int size, GrayF32& intensi
 	}
 }
 
+// the overload FastHessianFeatureDetector::detectOctave<GrayS32v> resolves to
+inline void hessian(const GrayS32v& ii, int skip, int size, GrayF32& intensity, int /*threads*/ = 1) { hessian_s32(ii, skip, size, intensity); }
+
 // F:alg/feature/describe/impl/ImplDescribeBinaryCompare_U8.java:47-101 (+ DescribePointBinaryCompare.process :67-98): unlike the F32
 // class, the border form shifts the word for EVERY pair, in bounds or not
 inline void brief_u8(const GrayU8v& image, int radius, int numPoints, const int* samplePoints /*[n][2]*/, const int* compare /*[n][2]*/, int c_x, int c_y,

@@ -370,6 +370,15 @@ void orc_hessian_s32(const int32_t* ii, int iiStart, int iiStride, int w, int h,
 	GrayF32 o = view(out);
 	hessian_s32(v, skip, size, o);
 }
+int orc_fh_detect_s32(const int32_t* ii, int iiStart, int iiStride, int w, int h, const orc_fh_cfg* cfg, double* out, int cap, int threads) {
+	GrayS32v v{(int32_t*)ii, iiStart, iiStride, w, h};
+	FastHessianFeatureDetector det(toFh(cfg));
+	det.threads = threads;
+	det.detect(v);
+	int n = (int)det.foundPoints.size();
+	for (int i = 0; i < n && i < cap; i++) { out[3 * i] = det.foundPoints[i].x; out[3 * i + 1] = det.foundPoints[i].y; out[3 * i + 2] = det.foundPoints[i].scale; }
+	return n;
+}
 void orc_brief_u8(const uint8_t* img, int start, int stride, int w, int h, int radius, int numPoints, const int* samplePoints, const int* compare, const double* xy,
 				  int n, int32_t* out) {
 	GrayU8v v{img, start, stride, w, h};

@@ -124,6 +124,7 @@ def lib():
             "orc_blur_median": (C.c_int, [IM, IM, C.c_int]),
             "orc_integral_u8": (None, [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int32), C.c_int, C.c_int]),
             "orc_hessian_s32": (None, [P(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, IM]),
+            "orc_fh_detect_s32": (C.c_int, [P(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, P(FhCfg), P(C.c_double), C.c_int, C.c_int]),
             "orc_brief_u8": (None, [P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_double), C.c_int, P(C.c_int32)]),
             "orc_ssd_corner": (C.c_int, [IM, IM, C.c_int, C.c_int, C.c_float, P(C.c_float)]),
             "orc_conv_down_norm": (C.c_int, [C.c_int, P(C.c_float), C.c_int, IM, IM, C.c_int]),
@@ -434,6 +435,20 @@ def hessian_s32(ii_s32, skip, size):
     out = Gray(w // skip, h // skip)
     lib().orc_hessian_s32(_fp(a, C.c_int32), 0, w, w, h, skip, size, out.c())
     return out.array().copy()
+
+
+def fh_detect_s32(ii_s32, cfg=None, threads=1):
+    """FastHessianFeatureDetector<GrayS32>.detect on the integral image of a GrayU8 frame."""
+    cfg = cfg or FhCfg()
+    a = np.ascontiguousarray(ii_s32, dtype=np.int32)
+    h, w = a.shape
+    cap = 1 << 16
+    while True:
+        out = np.zeros((cap, 3), dtype=np.float64)
+        n = lib().orc_fh_detect_s32(_fp(a, C.c_int32), 0, w, w, h, C.byref(cfg), _fp(out, C.c_double), cap, threads)
+        if n <= cap:
+            return out[:n].copy()
+        cap = n
 
 
 def brief_describe_u8(img_u8, xy, radius, samplePoints, compare):

@@ -798,6 +798,23 @@ def test_integer_variants_stage_level(api, orc):
     assert np.array_equal(b.processAll(xy), orc.brief_describe_u8(img, xy, 16, sp, cp))
 
 
+@pytest.mark.parametrize("w,h,seed", [(100, 120, 1), (400, 300, 2), (641, 479, 3), (1920, 1080, 4)])
+def test_fast_hessian_on_s32_integral(api, orc, w, h, seed):
+    """FastHessianFeatureDetector<GrayS32> on the integral image of a GrayU8 frame: fused octaves on integer taps, the
+    shared levels, the stand-alone kernels -- key points bit-exact and in the reference's order."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (127 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 25, (h, w))).clip(0, 255).astype(np.uint8)
+    ii = api.IntegralImageOps.transform(api.GrayU8.wrap(img))
+    for cfg, ocfg in [(api.ConfigFastHessian(), orc.FhCfg()),
+                      (api.ConfigFastHessian(detectThreshold=20.0, extractRadius=1, initialSize=9, numberScalesPerOctave=4, numberOfOctaves=3),
+                       orc.FhCfg(20.0, 1, -1, 1, 9, 4, 3, 6))]:
+        fh = api.FastHessianFeatureDetector(cfg)
+        fh.detect(ii)
+        exp = orc.fh_detect_s32(ii.array(), ocfg, threads=8)
+        assert len(exp) > 10 and np.array_equal(fh.getFoundPoints(), exp), (w, h)
+
+
 def test_associate_surf_basic(api, orc):
     """AssociateSurfBasic / WrapAssociateSurfBasic (TestAssociateSurfBasic.java literals + detected SURF features of two noise images)."""
     def feats(desc, white):
