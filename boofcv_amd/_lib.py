@@ -54,6 +54,7 @@ SIGNATURES = {
     "bhip_surf_destroy": (_i, [_vp]),
     "bhip_surf_detect_f32": (_i, [_vp, P(_fp), _ip, _ip, _i, _i, _i]),
     "bhip_surf_detect_dev_f32": (_i, [_vp, _vp, _ll, _i, _i, _i, _i]),
+    "bhip_surf_detect_u8": (_i, [_vp, P(_u8p), _ip, _ip, _i, _i, _i]),
     "bhip_surf_detect_planar_f32": (_i, [_vp, P(_fp), _i, _i, _i, _i, _i]),
     "bhip_surf_count": (_i, [_vp, _i, _ip]),
     "bhip_surf_fetch": (_i, [_vp, _i, _dp, _dp, _u8p, _dp]),

@@ -423,12 +423,16 @@ class DetectDescribePoint:
             if im.width != w or im.height != h:
                 raise IllegalArgumentException("all images of a batch must have the same shape")
         n = len(images)
-        ptrs = (C.POINTER(C.c_float) * n)(*[im._p() for im in images])
+        u8 = isinstance(images[0], GrayU8)
+        if any(isinstance(im, GrayU8) != u8 for im in images):
+            raise IllegalArgumentException("all images of a batch must have the same type")
+        ptrs = (C.POINTER(C.c_uint8 if u8 else C.c_float) * n)(*[im._p() for im in images])
         starts = (C.c_int * n)(*[im.startIndex for im in images])
         strides = (C.c_int * n)(*[im.stride for im in images])
         self._cache = {}
         self._batch = 0
-        _check(self.ctx, _lib.load().bhip_surf_detect_f32(self._h, ptrs, starts, strides, w, h, n))
+        fn = _lib.load().bhip_surf_detect_u8 if u8 else _lib.load().bhip_surf_detect_f32
+        _check(self.ctx, fn(self._h, ptrs, starts, strides, w, h, n))
         self._batch = n
         self._image = 0
 
@@ -558,14 +562,14 @@ class FactoryDetectDescribe:
 
     @staticmethod
     def surfFast(configDetector=None, configDesc=None, configOrientation=None, imageType=GrayF32, ctx=None):
-        if imageType is not GrayF32:
-            raise RuntimeError("only GrayF32 is implemented on the GPU (use the Java path)")
+        if imageType is not GrayF32 and imageType is not GrayU8:
+            raise RuntimeError("only GrayF32 and GrayU8 are implemented on the GPU (use the Java path)")
         return DetectDescribePoint(False, configDetector, configDesc, configOrientation, ctx)
 
     @staticmethod
     def surfStable(configDetector=None, configDescribe=None, configOrientation=None, imageType=GrayF32, ctx=None):
-        if imageType is not GrayF32:
-            raise RuntimeError("only GrayF32 is implemented on the GPU (use the Java path)")
+        if imageType is not GrayF32 and imageType is not GrayU8:
+            raise RuntimeError("only GrayF32 and GrayU8 are implemented on the GPU (use the Java path)")
         return DetectDescribePoint(True, configDetector, configDescribe, configOrientation, ctx)
 
 

@@ -29,7 +29,8 @@ int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out,
 int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out, bool u8 = false);
-int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, int inStride, int* out, int outStride, int width, int height);
+int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, long long inImageStride, int inStride, int* out, long long outImageStride, int outStride,
+							int width, int height, int batch);
 
 int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* dev_src, const double* dev_dst, int count, const long long* srcOff,
 								 const int* ns, const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit,
@@ -250,8 +251,9 @@ struct FhDetector {
 		}
 	}
 
+	bool plannedInt = false;
 	int prepare(bhip_ctx* ctx, int width, int height, int batch_) {
-		if (width != W || height != H) { BHIP_TRY(makePlan(ctx, width, height)); planExecution(); }
+		if (width != W || height != H || plannedInt != intTaps) { BHIP_TRY(makePlan(ctx, width, height)); planExecution(); plannedInt = intTaps; }
 		W = width; H = height; batch = batch_;
 		if (cap == 0) cap = 8192;
 		return allocate(ctx);
@@ -367,6 +369,7 @@ struct bhip_surf {
 	ImgView iiView;
 	int planarBands = 0;       // > 0: the last detect was colour SURF on that many bands (descriptor = planarBands * dof values)
 	DescPlanar planar{};
+	bool descOptions = false;  // the last detect needs `planar` passed to the describe kernel (colour bands and / or integer taps)
 	int dofOut() const { return tables.dof * (planarBands > 0 ? planarBands : 1); }
 };
 
@@ -429,20 +432,25 @@ static int buildTables(bhip_surf* s) {
 }
 
 // planarBands > 0: `in` holds [1 + planarBands] images -- the band average first, then the bands (colour SURF, one frame)
-static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0) {
+// u8: `in.data` points at dense 8-bit frames ([batch][H][W] bytes); the integral images are then GrayS32 and every stage runs on integer taps
+static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, bool u8 = false) {
 	bhip_ctx* ctx = s->ctx;
 	const int W = in.width, H = in.height;
 	s->haveResult = false;
+	s->det.intTaps = u8;
 	BHIP_TRY(s->det.prepare(ctx, W, H, batch));
 	const int nImages = planarBands > 0 ? 1 + planarBands : batch;
 	BHIP_TRY(s->iiBuf.reserve(ctx, (size_t)W * H * 4 * nImages));
 	s->W = W; s->H = H; s->batch = batch;
 	ImgViewW iiW{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
-	BHIP_TRY(bhip_launch_integral(ctx, in, iiW, nImages));
+	if (u8) BHIP_TRY(bhip_launch_integral_u8(ctx, (const unsigned char*)in.data, (long long)W * H, W, s->iiBuf.as<int>(), (long long)W * H, W, W, H, nImages));
+	else BHIP_TRY(bhip_launch_integral(ctx, in, iiW, nImages));
 	ImgView ii{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
 	s->iiView = ii;
 	s->planarBands = planarBands;
-	s->planar = DescPlanar{s->iiBuf.as<float>() + (long long)W * H, (long long)W * H * (1 + planarBands), (long long)W * H, planarBands, 1.0};
+	s->planar = DescPlanar{s->iiBuf.as<float>() + (long long)W * H, (long long)W * H * (1 + planarBands), (long long)W * H, planarBands,
+						   planarBands > 0 ? 1.0 : 2.0, u8};
+	s->descOptions = planarBands > 0 || u8;
 	BHIP_TRY(s->det.run(ctx, ii));
 	// exclusive prefix of counts -> start of every image in the compact result arrays
 	s->starts.assign(batch + 1, 0);
@@ -471,7 +479,7 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0) {
 		}
 	}
 	BHIP_TRY(bhip_launch_describe_ex(ctx, ii, s->det.sorted.as<KeyPoint>(), s->det.cap, s->startBuf.as<int>(), batch, 0, total, s->tables, nullptr,
-									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>(), perm, planarBands > 0 ? &s->planar : nullptr));
+									 s->angBuf.as<double>(), s->descBuf.as<double>(), s->whiteBuf.as<uint8_t>(), perm, s->descOptions ? &s->planar : nullptr));
 	// the host vector `starts` was handed to an async copy: make sure it is consumed before it can change
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	s->haveResult = true;
@@ -558,6 +566,25 @@ int bhip_surf_detect_planar_f32(bhip_surf* s, const float* const* bands, int num
 	return surfRun(s, in, 1, numBands);
 }
 
+// FactoryDetectDescribe.surfStable / surfFast on GrayU8 frames (integral type GrayS32, GIntegralImageOps.getIntegralType): same results
+// interface as bhip_surf_detect_f32
+int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* startIndex, const int* stride, int width, int height, int batch) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!img || width <= 0 || height <= 0 || batch <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image batch");
+	const size_t imgBytes = (size_t)width * height;
+	BHIP_TRY(s->inBuf.reserve(ctx, imgBytes * batch));
+	for (int i = 0; i < batch; i++) {
+		const int st = stride ? stride[i] : width;
+		if (!img[i] || st < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
+		BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width, img[i] + (startIndex ? startIndex[i] : 0), (size_t)st, (size_t)width, height,
+									   hipMemcpyHostToDevice, ctx->stream));
+	}
+	ImgView in{s->inBuf.as<float>(), (long long)width * height, width, width, height};   // only the pointer and the shape are used
+	return surfRun(s, in, batch, 0, true);
+}
+
 int bhip_surf_count(bhip_surf* s, int image, int* n) {
 	if (!s || !n) return BHIP_ERR_INVALID;
 	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
@@ -633,7 +660,7 @@ int bhip_surf_describe_points(bhip_surf* s, int image, const double* xy_scale, i
 	BHIP_TRY(s->tmpWhite.reserve(ctx, (size_t)n));
 	BHIP_HIP(ctx, hipMemcpyAsync(s->tmpKp.p, kps.data(), (size_t)n * sizeof(KeyPoint), hipMemcpyHostToDevice, ctx->stream));
 	BHIP_TRY(bhip_launch_describe_ex(ctx, s->iiView, s->tmpKp.as<KeyPoint>(), 0, nullptr, s->batch, image, n, s->tables, nullptr, s->tmpAng.as<double>(),
-									 s->tmpDesc.as<double>(), s->tmpWhite.as<uint8_t>(), nullptr, s->planarBands > 0 ? &s->planar : nullptr));
+									 s->tmpDesc.as<double>(), s->tmpWhite.as<uint8_t>(), nullptr, s->descOptions ? &s->planar : nullptr));
 	if (angle) BHIP_HIP(ctx, hipMemcpyAsync(angle, s->tmpAng.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
 	if (white) BHIP_HIP(ctx, hipMemcpyAsync(white, s->tmpWhite.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
 	if (desc) BHIP_HIP(ctx, hipMemcpyAsync(desc, s->tmpDesc.p, (size_t)n * 8 * dof, hipMemcpyDeviceToHost, ctx->stream));
@@ -1182,7 +1209,7 @@ int bhip_integral_u8_s32(bhip_ctx* ctx, const uint8_t* in, int inStart, int inSt
 	BHIP_TRY(sc->a.reserve(ctx, (size_t)width * height));
 	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
 	BHIP_HIP(ctx, hipMemcpy2DAsync(sc->a.p, (size_t)width, in + inStart, (size_t)inStride, (size_t)width, height, hipMemcpyHostToDevice, ctx->stream));
-	BHIP_TRY(bhip_launch_integral_u8(ctx, (const unsigned char*)sc->a.p, width, sc->b.as<int>(), width, width, height));
+	BHIP_TRY(bhip_launch_integral_u8(ctx, (const unsigned char*)sc->a.p, 0, width, sc->b.as<int>(), 0, width, width, height, 1));
 	BHIP_HIP(ctx, hipMemcpy2DAsync(out + outStart, (size_t)outStride * 4, sc->b.p, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;

@@ -150,12 +150,14 @@ struct HessLevelSource {
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
 						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr, bool intTaps = false);
 
-// colour SURF request for the describe kernel (see DescParams)
+// describe-kernel options beyond the grey float default (see DescParams): colour SURF bands (nBands > 0), the orientation's object
+// radius factor, integer taps (GrayS32 integral images)
 struct DescPlanar {
 	const float* data;               // band integral images, [image][band][H][W]
 	long long imageStride, bandStride;
 	int nBands;
 	double oriRadiusFactor;
+	bool intTaps;
 };
 struct DetectLevelParams {
 	int skip, w, h;              // intensity image size

@@ -79,7 +79,10 @@ __device__ __forceinline__ GradGeom makeGeom(int r, int stride, int W, int H) {
 	g.anyInside = (2 * r + 2 <= W) && (2 * r + 2 <= H);
 	return g;
 }
-__device__ __forceinline__ void gradSample(const float* __restrict__ d, const GradGeom& G, int x, int y, float& gx, float& gy) {
+// T = float (GrayF32 integral image: SparseIntegralGradient_NoBorder_F32) or int (GrayS32, the integral image of a GrayU8 frame:
+// SparseIntegralGradient_NoBorder_I32.java:46-76 -- integer box differences, handed on as exact values)
+template <class T>
+__device__ __forceinline__ void gradSample(const T* __restrict__ d, const GradGeom& G, int x, int y, T& gx, T& gy) {
 	const int r = G.r;
 	const bool inb = x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < G.W && y + r < G.H;
 	const int xs = inb ? x : G.safe, ys = inb ? y : G.safe;
@@ -90,16 +93,16 @@ __device__ __forceinline__ void gradSample(const float* __restrict__ d, const Gr
 	const int s3 = s2 + G.stride;
 	const int s4 = s3 + r * G.stride;
 	const int w = G.w;
-	const float p0 = d[s1], p1 = d[s1 + r], p2 = d[s1 + r + 1], p3 = d[s1 + w];
-	const float p11 = d[s2], p4 = d[s2 + w];
-	const float p10 = d[s3], p5 = d[s3 + w];
-	const float p9 = d[s4], p8 = d[s4 + r], p7 = d[s4 + r + 1], p6 = d[s4 + w];
-	const float left = p8 - p9 - p1 + p0;
-	const float right = p6 - p7 - p3 + p2;
-	const float top = p4 - p11 - p3 + p0;
-	const float bottom = p6 - p9 - p5 + p10;
-	gx = inb ? right - left : 0.0f;
-	gy = inb ? bottom - top : 0.0f;
+	const T p0 = d[s1], p1 = d[s1 + r], p2 = d[s1 + r + 1], p3 = d[s1 + w];
+	const T p11 = d[s2], p4 = d[s2 + w];
+	const T p10 = d[s3], p5 = d[s3 + w];
+	const T p9 = d[s4], p8 = d[s4 + r], p7 = d[s4 + r + 1], p6 = d[s4 + w];
+	const T left = p8 - p9 - p1 + p0;
+	const T right = p6 - p7 - p3 + p2;
+	const T top = p4 - p11 - p3 + p0;
+	const T bottom = p6 - p9 - p5 + p10;
+	gx = inb ? right - left : T(0);
+	gy = inb ? bottom - top : T(0);
 }
 
 // georegression UtilAngle.dist: circular distance in [0,pi]
@@ -130,8 +133,8 @@ struct OriSortOut {
 	double* dX; double* dY; double* sA;
 	float* sF;   // (float)sA, for the coarse window searches
 };
-template <int EPLT>
-__device__ __forceinline__ void permuteSorted(const float* gX, const float* gY, const unsigned short* srcI, const double (&a)[EPLT], const double* weights,
+template <int EPLT, class T>
+__device__ __forceinline__ void permuteSorted(const T* gX, const T* gY, const unsigned short* srcI, const double (&a)[EPLT], const double* weights,
 											   OriSortOut o, int p0, int cnt) {
 	double x[EPLT], y[EPLT];
 #pragma unroll
@@ -150,8 +153,8 @@ __device__ __forceinline__ void permuteSorted(const float* gX, const float* gY, 
 	waveSync();
 }
 
-template <int EPLT>
-__device__ __forceinline__ void sortSamplesByAngle(const float* gX, const float* gY, double* keyA, double* keyB, unsigned short* idxA, unsigned short* idxB,
+template <int EPLT, class T>
+__device__ __forceinline__ void sortSamplesByAngle(const T* gX, const T* gY, double* keyA, double* keyB, unsigned short* idxA, unsigned short* idxB,
 													const double* weights, OriSortOut out, int n, int lane) {
 	const int EPL = (n + 63) >> 6;   // <= EPLT
 	const int p0 = lane * EPL;
@@ -234,7 +237,7 @@ __device__ __forceinline__ void sortSamplesByAngle(const float* gX, const float*
 		double a[EPLT];
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) a[e] = e < cnt ? srcK[p0 + e] : 0.0;
-		permuteSorted<EPLT>(gX, gY, srcI, a, weights, out, p0, cnt);
+		permuteSorted<EPLT, T>(gX, gY, srcI, a, weights, out, p0, cnt);
 	}
 }
 
@@ -249,8 +252,8 @@ __device__ __forceinline__ unsigned int angleKey32(double a) {
 	const unsigned int u = __float_as_uint(f);
 	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-template <int EPLT>
-__device__ __forceinline__ bool sortSamplesFast32(const float* gX, const float* gY, const double* ang, unsigned int* keyA, unsigned int* keyB,
+template <int EPLT, class T>
+__device__ __forceinline__ bool sortSamplesFast32(const T* gX, const T* gY, const double* ang, unsigned int* keyA, unsigned int* keyB,
 												   unsigned short* idxA, unsigned short* idxB, const double* weights, OriSortOut out, int n, int lane) {
 	const int EPL = (n + 63) >> 6;   // <= EPLT
 	const int p0 = lane * EPL;
@@ -345,7 +348,7 @@ __device__ __forceinline__ bool sortSamplesFast32(const float* gX, const float* 
 			if (idn[e] >= 0 && (a[e] > an[e] || (a[e] == an[e] && id[e] > idn[e]))) bad = true;
 	}
 	if (__any(bad)) return false;
-	permuteSorted<EPLT>(gX, gY, srcI, a, weights, out, p0, cnt);
+	permuteSorted<EPLT, T>(gX, gY, srcI, a, weights, out, p0, cnt);
 	return true;
 }
 
@@ -574,7 +577,7 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 
 // EPLT = orientation samples per lane = ceil(n / 64), TWT = samples per sub-region row: compile-time for the common configurations so
 // the unrolled batches carry no dead slots (the kernel is issue bound); <8,16> is the generic instantiation.
-template <bool STAMP, int EPLT, int TWT>
+template <bool STAMP, int EPLT, int TWT, class TAP>
 __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ldsAll[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		local = (int)g;
 	}
 	const KeyPoint kp = P.imageStart ? P.kps[(long long)img * P.cap + local] : P.kps[local];
-	const float* __restrict__ d = P.ii.data + (long long)img * P.ii.imageStride;
+	const TAP* __restrict__ d = (const TAP*)P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const SurfTables& T = P.t;
 
@@ -624,24 +627,24 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		tl_y += 0.5;
 		const int sw = T.oriWidth, n = sw * sw;
 		// sort-phase layout (see sortSamplesByAngle); the average variant only stages its addends as dX, dY
-		float* gX = (float*)lds;
-		float* gY = gX + n;
+		TAP* gX = (TAP*)lds;
+		TAP* gY = gX + n;
 		double* ang = (double*)(lds + (size_t)8 * n);
 		double* keyB = (double*)(lds + (size_t)16 * n);
 		double* dX = (double*)lds;
 		double* dY = dX + n;
 		{
 			// all of this lane's samples: taps first (independent loads in flight together), then the fp64 tail
-			float gx[EPLT], gy[EPLT];
+			TAP gx[EPLT], gy[EPLT];
 #pragma unroll
 			for (int e = 0; e < EPLT; e++) {
 				const int idx = lane + 64 * e;
-				gx[e] = 0.0f; gy[e] = 0.0f;
+				gx[e] = TAP(0); gy[e] = TAP(0);
 				if (idx < n && G.anyInside) {
 					const int sy = idx / sw, sx = idx - sy * sw;
 					const int xx = (int)(tl_x + sx * period);
 					const int yy = (int)(tl_y + sy * period);
-					gradSample(d, G, xx, yy, gx[e], gy[e]);
+					gradSample<TAP>(d, G, xx, yy, gx[e], gy[e]);
 				}
 			}
 #pragma unroll
@@ -683,8 +686,8 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			const OriSortOut so{dX, dY, dY + n, (float*)(lds + (size_t)28 * n)};
 			const double* wts = T.oriHasWeights ? T.oriWeights : nullptr;
 			bool sorted = false;
-			if (!P.sort64) sorted = sortSamplesFast32<EPLT>(gX, gY, ang, (unsigned int*)keyB, (unsigned int*)keyB + n, idxA, idxB, wts, so, n, lane);
-			if (!sorted) sortSamplesByAngle<EPLT>(gX, gY, ang, keyB, idxA, idxB, wts, so, n, lane);
+			if (!P.sort64) sorted = sortSamplesFast32<EPLT, TAP>(gX, gY, ang, (unsigned int*)keyB, (unsigned int*)keyB + n, idxA, idxB, wts, so, n, lane);
+			if (!sorted) sortSamplesByAngle<EPLT, TAP>(gX, gY, ang, keyB, idxA, idxB, wts, so, n, lane);
 			ang = so.sA;   // sorted angles; dX, dY hold the sorted samples
 			DSTAMP(2);
 			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
@@ -745,13 +748,13 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const int overLap = T.stable ? T.overLap : 0;
 	const int gridW = regionSize + 2 * overLap;
 	const int nsamp = gridW * gridW;
-	float* sX = (float*)lds;
-	float* sY = sX + nsamp;
+	TAP* sX = (TAP*)lds;
+	TAP* sY = sX + nsamp;
 	double* feat = (double*)(sY + nsamp + (nsamp & 1));  // keep 8-byte alignment
 	// Laplacian sign (computeLaplaceSign): kernelDerivXX(9s) + kernelDerivYY(9s) at the rounded location = four clamped box sums of
 	// four corners each.  Lane t < 16 fetches corner (t & 3) of box (t >> 2) now; the sign is assembled at the end of the kernel, so
 	// the scattered loads are hidden behind the descriptor work.
-	float lapTap = 0.0f;
+	TAP lapTap = TAP(0);
 	if (P.white && lane < 16) {
 		const int x = (int)(kp.x + 0.5), y = (int)(kp.y + 0.5);
 		const int si = (int)ceil(scale);
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const int dof = T.dof;
 	const int nb = P.nBands > 0 ? P.nBands : 1;
 	for (int band = 0; band < nb; band++) {
-	const float* __restrict__ db = P.nBands > 0 ? P.bandData + (long long)img * P.bandImageStride + (long long)band * P.bandStride : d;
+	const TAP* __restrict__ db = P.nBands > 0 ? (const TAP*)P.bandData + (long long)img * P.bandImageStride + (long long)band * P.bandStride : d;
 	if (band > 0) waveSync();   // the previous band's sums have read sX, sY
 	{
 		// sample grid in 8x8 blocks: the 64 lanes of one pass cover a compact (8 scale)^2 patch of the image, so a wave-level gather
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		const int nblocks = blocksPerSide * blocksPerSide;
 		const int ly = lane >> 3, lx = lane & 7;
 		for (int b0 = 0; b0 < nblocks; b0 += 3) {
-			float gx[3], gy[3];
+			TAP gx[3], gy[3];
 			int at[3];
 #pragma unroll
 			for (int u = 0; u < 3; u++) {
@@ -790,14 +793,14 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				const int iy = 8 * by + ly, ix = 8 * bx + lx;
 				const bool on = b < nblocks && iy < gridW && ix < gridW;
 				at[u] = on ? iy * gridW + ix : -1;
-				gx[u] = 0.0f; gy[u] = 0.0f;
+				gx[u] = TAP(0); gy[u] = TAP(0);
 				if (on && G.anyInside) {
 					const int rY = iy - regionR - overLap, rX = ix - regionR - overLap;
 					const double regionY = rY * scale;
 					const double regionX = rX * scale;
 					const int pixelX = (int)(c_x + c * regionX - s * regionY);
 					const int pixelY = (int)(c_y + s * regionX + c * regionY);
-					gradSample(db, G, pixelX, pixelY, gx[u], gy[u]);
+					gradSample<TAP>(db, G, pixelX, pixelY, gx[u], gy[u]);
 				}
 			}
 #pragma unroll
@@ -820,13 +823,13 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		for (int i = 0; i < T_w; i++) {
 			const int index = (rY + regionR + i) * gridW + rX + regionR;
 			// one wait per row: the row's samples and weights are fetched together, then summed in the reference's order
-			float vx[TWT], vy[TWT];
+			TAP vx[TWT], vy[TWT];
 			double w[TWT];
 #pragma unroll
 			for (int j = 0; j < TWT; j++) {
 				const bool on = j < T_w;
-				vx[j] = on ? sX[index + j] : 0.0f;
-				vy[j] = on ? sY[index + j] : 0.0f;
+				vx[j] = on ? sX[index + j] : TAP(0);
+				vy[j] = on ? sY[index + j] : TAP(0);
 				w[j] = !on ? 0.0 : T.stable ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
 			}
 #pragma unroll
@@ -861,18 +864,19 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	}
 	if (P.white) {
 		// block_zero = br - tr - bl + tl per box, then xx = 0 + b0*1 + b1*(-3), yy likewise, lap = (double)xx + (double)yy
-		float bs[4];
+		TAP bs[4];
 #pragma unroll
 		for (int b = 0; b < 4; b++) {
-			const float br = __shfl(lapTap, 4 * b, 64), tr = __shfl(lapTap, 4 * b + 1, 64), bl = __shfl(lapTap, 4 * b + 2, 64), tl = __shfl(lapTap, 4 * b + 3, 64);
+			const TAP br = __shfl(lapTap, 4 * b, 64), tr = __shfl(lapTap, 4 * b + 1, 64), bl = __shfl(lapTap, 4 * b + 2, 64), tl = __shfl(lapTap, 4 * b + 3, 64);
 			bs[b] = br - tr - bl + tl;
 		}
-		float xx = 0;
-		xx += bs[0] * 1.0f;
-		xx += bs[1] * -3.0f;
-		float yy = 0;
-		yy += bs[2] * 1.0f;
-		yy += bs[3] * -3.0f;
+		// convolveSparse: ret = 0; ret += block * scale in the integral image's type (float scales for GrayF32, int for GrayS32), then widened
+		TAP xx = 0;
+		xx += bs[0] * TAP(1);
+		xx += bs[1] * TAP(-3);
+		TAP yy = 0;
+		yy += bs[2] * TAP(1);
+		yy += bs[3] * TAP(-3);
 		double lap = (double)xx;
 		lap += (double)yy;
 		if (lane == 0) P.white[g] = lap > 0 ? 1 : 0;
@@ -899,8 +903,10 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	P.anglesIn = anglesIn; P.angles = angles; P.desc = desc; P.white = white; P.perm = perm;
 	P.bandData = nullptr; P.bandImageStride = P.bandStride = 0; P.nBands = 0; P.oriRadiusFactor = 2.0;
 	if (planar) {
-		if (planar->nBands < 1 || !planar->data) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad planar description request");
-		P.bandData = planar->data; P.bandImageStride = planar->imageStride; P.bandStride = planar->bandStride; P.nBands = planar->nBands;
+		if (planar->nBands > 0) {
+			if (!planar->data) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad planar description request");
+			P.bandData = planar->data; P.bandImageStride = planar->imageStride; P.bandStride = planar->bandStride; P.nBands = planar->nBands;
+		}
 		P.oriRadiusFactor = planar->oriRadiusFactor;
 	}
 	P.ldsPerWave = bhip_describe_lds_bytes(t, P.nBands);
@@ -923,8 +929,8 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 			{
 				const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
 				const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
-				if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<true, 5, 9>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
-				else hipLaunchKernelGGL((k_describe<true, 8, 16>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+				if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<true, 5, 9, float>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+				else hipLaunchKernelGGL((k_describe<true, 8, 16, float>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 			}
 			std::vector<unsigned long long> h((size_t)total * 16);
 			(void)hipMemcpy(h.data(), dev, (size_t)total * 64, hipMemcpyDeviceToHost);
@@ -961,9 +967,13 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 		const dim3 grid((unsigned)blocks), block(256);
 		size_t ldsBytes = (size_t)P.ldsPerWave * 4;
 		{ const char* e = getenv("BHIP_DESCRIBE_LDSPAD"); if (e) ldsBytes += (size_t)atoi(e); }   // occupancy experiments only
-		if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9>), grid, block, ldsBytes, ctx->stream, P);        // surfStable defaults
-		else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5>), grid, block, ldsBytes, ctx->stream, P);   // surfFast defaults
-		else hipLaunchKernelGGL((k_describe<false, 8, 16>), grid, block, ldsBytes, ctx->stream, P);
+		if (planar && planar->intTaps) {   // GrayS32 integral image(s)
+			if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9, int>), grid, block, ldsBytes, ctx->stream, P);
+			else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5, int>), grid, block, ldsBytes, ctx->stream, P);
+			else hipLaunchKernelGGL((k_describe<false, 8, 16, int>), grid, block, ldsBytes, ctx->stream, P);
+		} else if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9, float>), grid, block, ldsBytes, ctx->stream, P);        // surfStable defaults
+		else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5, float>), grid, block, ldsBytes, ctx->stream, P);   // surfFast defaults
+		else hipLaunchKernelGGL((k_describe<false, 8, 16, float>), grid, block, ldsBytes, ctx->stream, P);
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

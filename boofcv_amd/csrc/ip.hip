@@ -652,11 +652,12 @@ int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out,
 // IntegralImageOps.transform(GrayU8, GrayS32)   I:alg/transform/ii/impl/ImplIntegralImageOps.java:94-118.  Integer sums are exact in any
 // order, so the row pass is a wave-parallel scan (one wave per row, 64 pixels per step with a carry) and the column pass one thread per
 // column.  Bound: HBM (P read as bytes, 4P written, then 8P for the column pass).
-__global__ __launch_bounds__(256) void k_integral_rows_u8(const unsigned char* __restrict__ in, int inStride, int* __restrict__ out, int outStride, int width, int height) {
+__global__ __launch_bounds__(256) void k_integral_rows_u8(const unsigned char* __restrict__ in, long long inImageStride, int inStride, int* __restrict__ out,
+														  long long outImageStride, int outStride, int width, int height) {
 	const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (row >= height) return;
-	const unsigned char* r = in + (long long)row * inStride;
-	int* o = out + (long long)row * outStride;
+	const unsigned char* r = in + (long long)blockIdx.y * inImageStride + (long long)row * inStride;
+	int* o = out + (long long)blockIdx.y * outImageStride + (long long)row * outStride;
 	int carry = 0;
 	for (int x0 = 0; x0 < width; x0 += 64) {
 		const int x = x0 + lane;
@@ -670,24 +671,27 @@ __global__ __launch_bounds__(256) void k_integral_rows_u8(const unsigned char* _
 		carry += __shfl(v, 63, 64);
 	}
 }
-__global__ __launch_bounds__(256) void k_integral_cols_s32(int* __restrict__ io, int stride, int width, int height) {
+__global__ __launch_bounds__(256) void k_integral_cols_s32(int* __restrict__ io, long long imageStride, int stride, int width, int height) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= width) return;
+	int* p = io + (long long)blockIdx.y * imageStride;
 	int total = 0;
 	for (int y = 0; y < height; y++) {
-		total += io[(long long)y * stride + x];
-		io[(long long)y * stride + x] = total;
+		total += p[(long long)y * stride + x];
+		p[(long long)y * stride + x] = total;
 	}
 }
-int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, int inStride, int* out, int outStride, int width, int height) {
-	if (width <= 0 || height <= 0) return BHIP_OK;
+int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, long long inImageStride, int inStride, int* out, long long outImageStride, int outStride,
+							int width, int height, int batch) {
+	if (width <= 0 || height <= 0 || batch <= 0) return BHIP_OK;
 	{
-		ProfScope prof(ctx, "k_integral_rows_u8", 5.0 * width * height);
-		hipLaunchKernelGGL(k_integral_rows_u8, dim3((height + 3) / 4), dim3(256), 0, ctx->stream, in, inStride, out, outStride, width, height);
+		ProfScope prof(ctx, "k_integral_rows_u8", 5.0 * width * height * batch);
+		hipLaunchKernelGGL(k_integral_rows_u8, dim3((height + 3) / 4, batch), dim3(256), 0, ctx->stream, in, inImageStride, inStride, out, outImageStride, outStride,
+						   width, height);
 	}
 	{
-		ProfScope prof(ctx, "k_integral_cols_s32", 8.0 * width * height);
-		hipLaunchKernelGGL(k_integral_cols_s32, dim3((width + 255) / 256), dim3(256), 0, ctx->stream, out, outStride, width, height);
+		ProfScope prof(ctx, "k_integral_cols_s32", 8.0 * width * height * batch);
+		hipLaunchKernelGGL(k_integral_cols_s32, dim3((width + 255) / 256, batch), dim3(256), 0, ctx->stream, out, outImageStride, outStride, width, height);
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

@@ -115,6 +115,11 @@ int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long im
  * orientation object radius = scale) -> DescribePointSurfPlanar.describe (F:alg/feature/describe/DescribePointSurfPlanar.java:100-114;
  * bands concatenated, normalised once; Laplacian sign from the average).  Results through bhip_surf_count / _fetch / _dev_view with
  * image = 0; bhip_surf_dof() then returns numBands * 64.  getRadius(i) of this wrapper is the scale itself (no factor 2). */
+/* The same on GrayU8 frames: the integral images are GrayS32 (GIntegralImageOps.getIntegralType) and every stage runs on integer taps --
+ * IntegralImageOps.transform(GrayU8, GrayS32), FastHessianFeatureDetector<GrayS32>, SparseIntegralGradient_NoBorder_I32 for the
+ * orientation and the descriptor, convolveSparse(GrayS32) for the Laplacian sign.  Results through the same count / fetch calls;
+ * bhip_surf_fetch_integral then returns the int32 words. */
+int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* startIndex, const int* stride, int width, int height, int batch);
 int bhip_surf_detect_planar_f32(bhip_surf* s, const float* const* bands, int numBands, int startIndex, int stride, int width, int height);
 int bhip_surf_count(bhip_surf* s, int image, int* n);
 /* getLocation(i)/scale -> xy_scale[3n] ; getOrientation(i) -> angle[n] ; BrightFeature.white -> white[n] ;

@@ -217,6 +217,23 @@ inline float convolveSparse(const GrayF32& ii, const IntegralKernel& k, int x, i
 	return ret;
 }
 
+// the same on a view whose 32-bit words are int32 (GrayS32 integral image): ImplIntegralImageOps.java:239-258 block_zero(GrayS32) + convolveSparse
+inline int32_t convolveSparseInt(const GrayF32& iiView, const IntegralKernel& k, int x, int y) {
+	const int32_t* d = reinterpret_cast<const int32_t*>(iiView.data);
+	int32_t ret = 0;
+	for (int i = 0; i < k.n; i++) {
+		int x0 = std::min(x + k.x0[i], iiView.width - 1), y0 = std::min(y + k.y0[i], iiView.height - 1);
+		int x1 = std::min(x + k.x1[i], iiView.width - 1), y1 = std::min(y + k.y1[i], iiView.height - 1);
+		int32_t br = 0, tr = 0, bl = 0, tl = 0;
+		if (x1 >= 0 && y1 >= 0) br = d[iiView.startIndex + y1 * iiView.stride + x1];
+		if (y0 >= 0 && x1 >= 0) tr = d[iiView.startIndex + y0 * iiView.stride + x1];
+		if (x0 >= 0 && y1 >= 0) bl = d[iiView.startIndex + y1 * iiView.stride + x0];
+		if (x0 >= 0 && y0 >= 0) tl = d[iiView.startIndex + y0 * iiView.stride + x0];
+		ret += (br - tr - bl + tl) * k.scales[i];
+	}
+	return ret;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hessian-determinant intensity   F:alg/feature/detect/intensity/impl/ImplIntegralImageFeatureIntensity.java
 // ------------------------------------------------------------------------------------------------
@@ -660,8 +677,34 @@ struct SparseIntegralGradient_NoBorder_F32 {
 	}
 	// T:struct/sparse/SparseScaleGradient.java:48-50
 	bool isInBounds(int x, int y) const { return x + x0 >= 0 && y + y0 >= 0 && x + x1 < input->width && y + y1 < input->height; }
+	// GrayS32 integral image (of a GrayU8 frame): `input` is then a view whose 32-bit words are int32 and the taps are combined in integer
+	// arithmetic (I:alg/transform/ii/impl/SparseIntegralGradient_NoBorder_I32.java:46-76).  GradientValue_I32.getX() hands the consumer a
+	// double; here the value travels as a float, which is exact below 2^24 (checked) -- 255 * (2r+1) * r stays below that for r < 180.
+	bool intPixels = false;
+	void computeInt(int x, int y, float& gx, float& gy) const {
+		const GrayF32& in = *input;
+		const int32_t* d = reinterpret_cast<const int32_t*>(in.data);
+		int horizontalOffset = x - r - 1;
+		int indexSrc1 = in.startIndex + (y - r - 1) * in.stride + horizontalOffset;
+		int indexSrc2 = indexSrc1 + r * in.stride;
+		int indexSrc3 = indexSrc2 + in.stride;
+		int indexSrc4 = indexSrc3 + r * in.stride;
+		int32_t p0 = d[indexSrc1], p1 = d[indexSrc1 + r], p2 = d[indexSrc1 + r + 1], p3 = d[indexSrc1 + w];
+		int32_t p11 = d[indexSrc2], p4 = d[indexSrc2 + w];
+		int32_t p10 = d[indexSrc3], p5 = d[indexSrc3 + w];
+		int32_t p9 = d[indexSrc4], p8 = d[indexSrc4 + r], p7 = d[indexSrc4 + r + 1], p6 = d[indexSrc4 + w];
+		int32_t left = p8 - p9 - p1 + p0;
+		int32_t right = p6 - p7 - p3 + p2;
+		int32_t top = p4 - p11 - p3 + p0;
+		int32_t bottom = p6 - p9 - p5 + p10;
+		int32_t ix = right - left, iy = bottom - top;
+		if (std::abs((long long)ix) >= (1 << 24) || std::abs((long long)iy) >= (1 << 24)) throw std::runtime_error("integer gradient does not fit a float exactly");
+		gx = (float)ix;
+		gy = (float)iy;
+	}
 	// _F32.java:46-76
 	void compute(int x, int y, float& gx, float& gy) const {
+		if (intPixels) { computeInt(x, y, gx, gy); return; }
 		const GrayF32& in = *input;
 		int horizontalOffset = x - r - 1;
 		int indexSrc1 = in.startIndex + (y - r - 1) * in.stride + horizontalOffset;
@@ -746,6 +789,7 @@ struct OrientationIntegralBase {
 		g.setWidth(scale * kernelWidth);
 	}
 	void setImage(const GrayF32& integral) { ii = &integral; g.input = &integral; }
+	void setIntPixels(bool v) { g.intPixels = v; }
 };
 
 // impl/ImplOrientationSlidingWindowIntegral.java
@@ -963,6 +1007,8 @@ struct DescribePointSurf {
 	virtual ~DescribePointSurf() {}
 
 	void setImage(const GrayF32& integral) { ii = &integral; gradient.input = &integral; }
+	bool intPixels = false;   // see SparseIntegralGradient::intPixels
+	void setIntPixels(bool v) { intPixels = v; gradient.intPixels = v; }
 
 	// :169-179 describe(x,y,angle,scale,BrightFeature)
 	void describe(double x, double y, double angle, double scale, BrightFeature& ret) {
@@ -1025,6 +1071,12 @@ struct DescribePointSurf {
 		int s = (int)std::ceil(scale);
 		IntegralKernel kerXX = kernelDerivXX(9 * s);
 		IntegralKernel kerYY = kernelDerivYY(9 * s);
+		if (intPixels) {
+			// GIntegralImageOps.convolveSparse(GrayS32) returns an int that is widened to double
+			double lapI = (double)convolveSparseInt(*ii, kerXX, x, y);
+			lapI += (double)convolveSparseInt(*ii, kerYY, x, y);
+			return lapI > 0;
+		}
 		double lap = convolveSparse(*ii, kerXX, x, y);
 		lap += convolveSparse(*ii, kerYY, x, y);
 		return lap > 0;
@@ -1123,6 +1175,7 @@ struct DetectDescribeSurf {
 	DescribePointSurfMod describeMod;
 	DescribePointSurf describeFast;
 	GrayF32 ii;
+	bool intPixels = false;   // ii holds int32 words: the GrayS32 integral image of a GrayU8 frame (detectU8 in boof_oracle_int.hpp)
 	int threads = 1;
 
 	DetectDescribeSurf(bool stable_, const ConfigFastHessian& fh = ConfigFastHessian(), const ConfigSurfDescribe& sd = ConfigSurfDescribe(),
@@ -1133,6 +1186,7 @@ struct DetectDescribeSurf {
 
 	// WrapDetectDescribeSurf.java:93-128 (threads>1: WrapDetectDescribeSurf_MT.java:45-61, keypoint blocks in parallel)
 	void detect(const GrayF32& input, SurfResult& out) {
+		intPixels = false;
 		ii.reshape(input.width, input.height);
 		integral_transform(input, ii);
 		detector.threads = threads;
@@ -1214,6 +1268,7 @@ struct DetectDescribeSurf {
 			DescribePointSurfMod dm = describeMod;
 			DescribePointSurf df = describeFast;
 			os.setImage(ii); oa.setImage(ii); dm.setImage(ii); df.setImage(ii);
+			os.setIntPixels(intPixels); oa.setIntPixels(intPixels); dm.setIntPixels(intPixels); df.setIntPixels(intPixels);
 			BrightFeature bf;
 #pragma omp for schedule(dynamic, 16)
 			for (int i = 0; i < n; i++) {

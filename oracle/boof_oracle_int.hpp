@@ -109,6 +109,18 @@ inline void hessian_s32(const GrayS32v& ii, int skip, int size, GrayF32& intensi
 // the overload FastHessianFeatureDetector::detectOctave<GrayS32v> resolves to
 inline void hessian(const GrayS32v& ii, int skip, int size, GrayF32& intensity, int /*threads*/ = 1) { hessian_s32(ii, skip, size, intensity); }
 
+// FactoryDetectDescribe.surfStable / surfFast on GrayU8 (integral type GrayS32): WrapDetectDescribeSurf.detect with
+// GIntegralImageOps.transform(GrayU8, GrayS32), FastHessianFeatureDetector<GrayS32>, orientation and descriptor on I32 gradients
+inline void surfDetectU8(DetectDescribeSurf& dd, const GrayU8v& input, SurfResult& out) {
+	dd.ii.reshape(input.width, input.height);   // float storage reused as 32-bit words
+	GrayS32v v{reinterpret_cast<int32_t*>(dd.ii.data), dd.ii.startIndex, dd.ii.stride, input.width, input.height};
+	integral_transform_u8(input, v);
+	dd.intPixels = true;
+	dd.detector.threads = dd.threads;
+	dd.detector.detect(v);
+	dd.describeAll(dd.detector.foundPoints, out);
+}
+
 // F:alg/feature/describe/impl/ImplDescribeBinaryCompare_U8.java:47-101 (+ DescribePointBinaryCompare.process :67-98): unlike the F32
 // class, the border form shifts the word for EVERY pair, in bounds or not
 inline void brief_u8(const GrayU8v& image, int radius, int numPoints, const int* samplePoints /*[n][2]*/, const int* compare /*[n][2]*/, int c_x, int c_y,

@@ -233,6 +233,13 @@ int orc_surf_describe_points_planar(void* h, const double* xys, int n, int threa
 	s->dd->describeAllPlanar(pts, s->res);
 	return n;
 }
+int orc_surf_detect_u8(void* h, const uint8_t* img, int start, int stride, int w, int hh, int threads) {
+	orc_surf* s = (orc_surf*)h;
+	s->dd->threads = threads;
+	GrayU8v v{img, start, stride, w, hh};
+	surfDetectU8(*s->dd, v, s->res);
+	return (int)s->res.points.size();
+}
 void orc_surf_fetch(void* h, double* xys, double* angle, uint8_t* white, double* desc) {
 	orc_surf* s = (orc_surf*)h;
 	size_t n = s->res.points.size();

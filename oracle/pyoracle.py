@@ -99,6 +99,7 @@ def lib():
             "orc_surf_destroy": (None, [C.c_void_p]),
             "orc_surf_detect": (C.c_int, [C.c_void_p, IM, C.c_int]),
             "orc_surf_describe_points": (C.c_int, [C.c_void_p, IM, P(C.c_double), C.c_int, C.c_int]),
+            "orc_surf_detect_u8": (C.c_int, [C.c_void_p, P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
             "orc_surf_detect_planar": (C.c_int, [C.c_void_p, P(_Image), C.c_int, C.c_int]),
             "orc_surf_describe_points_planar": (C.c_int, [C.c_void_p, P(C.c_double), C.c_int, C.c_int]),
             "orc_surf_fetch": (None, [C.c_void_p, P(C.c_double), P(C.c_double), P(C.c_uint8), P(C.c_double)]),
@@ -288,6 +289,15 @@ class Surf:
         self.n = lib().orc_surf_detect(self._h, img.c(), threads)
         self._bands = 1
         self._shape = (img.width, img.height)
+        return self.n
+
+    def detect_u8(self, img_u8, threads=1):
+        """FactoryDetectDescribe.surfStable / surfFast on a GrayU8 frame ((H, W) uint8 array)."""
+        a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+        h, w = a.shape
+        self.n = lib().orc_surf_detect_u8(self._h, _fp(a, C.c_uint8), 0, w, w, h, threads)
+        self._bands = 1
+        self._shape = (w, h)
         return self.n
 
     def detect_planar(self, bands, threads=1):

@@ -815,6 +815,43 @@ def test_fast_hessian_on_s32_integral(api, orc, w, h, seed):
         assert len(exp) > 10 and np.array_equal(fh.getFoundPoints(), exp), (w, h)
 
 
+@pytest.mark.parametrize("stable", [True, False])
+def test_surf_on_gray_u8(api, orc, stable):
+    """FactoryDetectDescribe.surfStable / surfFast(..., GrayU8): GrayS32 integral image, every stage on integer taps.
+    Key points and Laplacian signs bit-exact, descriptors inside the 1e-5 bar; a batch equals frame by frame; sub-image frames; and on a
+    frame small enough for a float integral image to be exact, the GrayU8 and the GrayF32 pipelines agree."""
+    rng = np.random.default_rng(31)
+    frames = []
+    for (w, h) in [(240, 200), (640, 480), (1920, 1080)]:
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames.append((127 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 25, (h, w))).clip(0, 255).astype(np.uint8))
+    fac = api.FactoryDetectDescribe.surfStable if stable else api.FactoryDetectDescribe.surfFast
+    dd = fac(None, None, None, api.GrayU8)
+    ref = orc.Surf(stable)
+    for img in frames:
+        dd.detect(api.GrayU8.wrap(img))
+        got = dd._results()
+        n = ref.detect_u8(img, threads=8)
+        pts, ang, white, desc = ref.fetch()
+        assert n > 100 and np.array_equal(got[0], pts) and np.array_equal(got[2], white)
+        assert np.median(np.abs(np.angle(np.exp(1j * (got[1] - ang))))) < 1e-12
+        derr = np.max(np.abs(got[3] - desc), axis=1)
+        assert (derr <= DESC_TOL).mean() >= 0.999, (img.shape, derr.max())
+    # batch of equal-sized frames == frame by frame; sub-image input
+    a, b = frames[0], np.ascontiguousarray(frames[1][:200, :240])
+    dd.detectBatch([api.GrayU8.wrap(a), api.GrayU8.wrap(b)])
+    batch = [tuple(np.array(x) for x in dd._results(i)) for i in range(2)]
+    big = np.zeros((220, 260), np.uint8); big[10:210, 12:252] = a
+    for i, im in enumerate([api.GrayU8(240, 200, big.reshape(-1), 10 * 260 + 12, 260), api.GrayU8.wrap(b)]):
+        dd.detect(im)
+        assert all(np.array_equal(x, y) for x, y in zip(dd._results(), batch[i]))
+    # 240 x 200 x 255 < 2^24: the float integral image is exact, so the float pipeline on the same pixel values gives the same features
+    ddf = fac(None, None, None, api.GrayF32)
+    ddf.detect(api.GrayF32.wrap(a.astype(np.float32)))
+    f = ddf._results()
+    assert np.array_equal(f[0], batch[0][0]) and np.array_equal(f[2], batch[0][2]) and np.max(np.abs(f[3] - batch[0][3])) < 1e-12
+
+
 def test_associate_surf_basic(api, orc):
     """AssociateSurfBasic / WrapAssociateSurfBasic (TestAssociateSurfBasic.java literals + detected SURF features of two noise images)."""
     def feats(desc, white):
