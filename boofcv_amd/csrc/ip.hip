@@ -676,7 +676,15 @@ __global__ __launch_bounds__(256) void k_integral_cols_s32(int* __restrict__ io,
 	if (x >= width) return;
 	int* p = io + (long long)blockIdx.y * imageStride;
 	int total = 0;
-	for (int y = 0; y < height; y++) {
+	int y = 0;
+	for (; y + 8 <= height; y += 8) {   // eight independent loads in flight, then the carry chain
+		int v[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) v[k] = p[(long long)(y + k) * stride + x];
+#pragma unroll
+		for (int k = 0; k < 8; k++) { total += v[k]; p[(long long)(y + k) * stride + x] = total; }
+	}
+	for (; y < height; y++) {
 		total += p[(long long)y * stride + x];
 		p[(long long)y * stride + x] = total;
 	}

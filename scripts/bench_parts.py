@@ -113,13 +113,24 @@ def config5(ctx, L, batch=8, w=3840, h=2160):
             "alg_GBs": round(alg * batch / dt / 1e9, 1), "kernels_ms": k}
 
 
+def config2_u8(ctx, L, batch=64, w=1920, h=1080):
+    """detect + describe on GrayU8 frames (host -> device upload included: the C ABI for U8 takes host buffers)."""
+    import bench
+    frames = bench.synth_frames(batch, h, w, 1000, torch.device("cuda")).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayU8, ctx=ctx)
+    imgs = [api.GrayU8.wrap(f) for f in frames]
+    dt, k = timed(ctx, lambda: dd.detectBatch(imgs), reps=3, warm=1)
+    return {"part": "config2 on GrayU8 frames (detect + describe, host frames)", "batch": batch, "ms": round(dt * 1e3, 2), "frames_per_s": round(batch / dt, 1),
+            "keypoints_per_frame": round(dd.totalFeatures() / batch, 1), "kernels_ms": k}
+
+
 def main():
     torch.cuda.set_device(0)
     ctx = api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream)
     L = _lib.load()
     which = sys.argv[1:] or ["3", "4", "5"]
     for wname in which:
-        r = {"3": config3, "4": config4, "5": config5}[wname](ctx, L)
+        r = {"3": config3, "4": config4, "5": config5, "2u8": config2_u8}[wname](ctx, L)
         print(json.dumps(r), flush=True)
 
 
