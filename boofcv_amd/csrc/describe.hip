@@ -748,9 +748,10 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const int overLap = T.stable ? T.overLap : 0;
 	const int gridW = regionSize + 2 * overLap;
 	const int nsamp = gridW * gridW;
-	TAP* sX = (TAP*)lds;
-	TAP* sY = sX + nsamp;
-	double* feat = (double*)(sY + nsamp + (nsamp & 1));  // keep 8-byte alignment
+	// the samples are widened to double once, when they are stored (each is read by up to 16 output lanes in the sums below)
+	double* sX = (double*)lds;
+	double* sY = sX + nsamp;
+	double* feat = sY + nsamp;
 	// Laplacian sign (computeLaplaceSign): kernelDerivXX(9s) + kernelDerivYY(9s) at the rounded location = four clamped box sums of
 	// four corners each.  Lane t < 16 fetches corner (t & 3) of box (t >> 2) now; the sign is assembled at the end of the kernel, so
 	// the scattered loads are hidden behind the descriptor work.
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			}
 #pragma unroll
 			for (int u = 0; u < 3; u++)
-				if (at[u] >= 0) { sX[at[u]] = gx[u]; sY[at[u]] = gy[u]; }
+				if (at[u] >= 0) { sX[at[u]] = (double)gx[u]; sY[at[u]] = (double)gy[u]; }
 		}
 	}
 	waveSync();
@@ -823,20 +824,20 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		for (int i = 0; i < T_w; i++) {
 			const int index = (rY + regionR + i) * gridW + rX + regionR;
 			// one wait per row: the row's samples and weights are fetched together, then summed in the reference's order
-			TAP vx[TWT], vy[TWT];
+			double vx[TWT], vy[TWT];
 			double w[TWT];
 #pragma unroll
 			for (int j = 0; j < TWT; j++) {
 				const bool on = j < T_w;
-				vx[j] = on ? sX[index + j] : TAP(0);
-				vy[j] = on ? sY[index + j] : TAP(0);
+				vx[j] = on ? sX[index + j] : 0.0;
+				vy[j] = on ? sY[index + j] : 0.0;
 				w[j] = !on ? 0.0 : T.stable ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
 			}
 #pragma unroll
 			for (int j = 0; j < TWT; j++) {
 				if (j < T_w) {
-					const double dx = w[j] * (double)vx[j];
-					const double dy = w[j] * (double)vy[j];
+					const double dx = w[j] * vx[j];
+					const double dy = w[j] * vy[j];
 					const double v = cA * dx + cB * dy;
 					sum += __longlong_as_double((long long)((unsigned long long)__double_as_longlong(v) & absMask));
 				}
@@ -890,7 +891,7 @@ int bhip_describe_lds_bytes(const SurfTables& t, int nBands) {
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
-	const int desc = (2 * ns + (ns & 1)) * 4 + t.dof * 8 * (nBands > 0 ? nBands : 1);
+	const int desc = 2 * ns * 8 + t.dof * 8 * (nBands > 0 ? nBands : 1);
 	int b = ori > desc ? ori : desc;
 	return (b + 15) & ~15;
 }
