@@ -66,6 +66,7 @@ SIGNATURES = {
     "bhip_integral_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _fp, _i, _i]),
     "bhip_hessian_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _fp, _i, _i]),
     "bhip_nonmax_block_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _f, _i, _i16p, _i, _ip]),
+    "bhip_select_nbest_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i16p, _i, _i, _i, _i16p, _ip]),
     "bhip_fh_detect_f32": (_i, [_vp, P(FhCfg), _fp, _i, _i, _i, _i, _dp, _i, _ip]),
     "bhip_assoc_l2_f64": (_i, [_vp, _dp, _i, _dp, _i, _i, _d, _i, _i, _ip, _dp]),
     "bhip_assoc_hamming": (_i, [_vp, _i32p, _i, _i32p, _i, _i, _d, _i, _ip, _dp]),

@@ -888,6 +888,31 @@ class FactoryFeatureExtractor:
         return NonMaxSuppression(config, ctx)
 
 
+class SelectNBestFeatures:
+    """F:alg/feature/detect/extract/SelectNBestFeatures.java:31-97: keep the N most intense corners.  The order of the kept corners is
+    the order ddogleg's QuickSelect leaves them in; the GPU runs the restated routine (see include/boofhip.h: order unpinned vs the jar)."""
+
+    def __init__(self, N, ctx=None):
+        self.ctx = _ctx(ctx)
+        self.target = N
+        self.bestCorners = []
+
+    def setN(self, N):
+        self.target = N
+
+    def process(self, intensityImage, origCorners, positive):
+        xy = np.array([[p.x, p.y] for p in origCorners], dtype=np.int16).reshape(-1, 2)
+        out = np.zeros((max(len(xy), 1), 2), dtype=np.int16)
+        n = C.c_int(0)
+        _check(self.ctx, _lib.load().bhip_select_nbest_f32(self.ctx._h, intensityImage._p(), intensityImage.startIndex, intensityImage.stride,
+                                                          intensityImage.width, intensityImage.height, xy.ctypes.data_as(_lib._i16p), len(xy),
+                                                          int(self.target), 1 if positive else 0, out.ctypes.data_as(_lib._i16p), C.byref(n)))
+        self.bestCorners = [Point2D_I16(int(x), int(y)) for x, y in out[:n.value]]
+
+    def getBestCorners(self):
+        return self.bestCorners
+
+
 class GradientCornerIntensity:
     """FactoryIntensityPointAlg.shiTomasi / harris (unweighted, GrayF32 derivatives): ImplSsdCorner_F32 with ShiTomasiCorner_F32 /
     HarrisCorner_F32 (F:alg/feature/detect/intensity/impl/ImplSsdCorner_F32.java:62-196).  Single-threaded summation order."""
@@ -931,8 +956,8 @@ class FactoryIntensityPointAlg:
 
 class GeneralFeatureDetector:
     """F:alg/feature/detect/interest/GeneralFeatureDetector.java:67-160 for a gradient corner intensity and a maxima extractor:
-    intensity.process -> extractor.process.  maxFeatures > 0 selects with ddogleg's QuickSelect, whose order is not pinned by the
-    reference tree -> RuntimeError (use the Java path)."""
+    intensity.process -> extractor.process -> selectBest (maxFeatures > 0: SelectNBestFeatures, :143-160).  Exclusion lists are not
+    mirrored (the trackers that pass them stay in Java)."""
 
     def __init__(self, intensity, extractor):
         self.intensity, self.extractor = intensity, extractor
@@ -941,10 +966,9 @@ class GeneralFeatureDetector:
         self.maxFeatures = 0
         self.intensityImage = GrayF32(1, 1)
         self.foundMaximum = []
+        self.selectBest = SelectNBestFeatures(10, intensity.ctx)
 
     def setMaxFeatures(self, n):
-        if n > 0:
-            raise RuntimeError("maxFeatures > 0 (QuickSelect order unpinned): use the Java path")
         self.maxFeatures = n
 
     def getRequiresGradient(self):
@@ -962,6 +986,10 @@ class GeneralFeatureDetector:
     def process(self, image, derivX, derivY, derivXX=None, derivYY=None, derivXY=None):
         self.intensity.process(derivX, derivY, self.intensityImage)
         self.foundMaximum = self.extractor.process(self.intensityImage)
+        if self.maxFeatures > 0:   # GeneralFeatureDetector.java:143-160 (numSelectMax = maxFeatures without an exclusion list)
+            self.selectBest.setN(self.maxFeatures)
+            self.selectBest.process(self.intensityImage, self.foundMaximum, True)
+            self.foundMaximum = list(self.selectBest.getBestCorners())
 
     def getIntensity(self):
         return self.intensityImage

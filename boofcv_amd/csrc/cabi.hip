@@ -157,7 +157,8 @@ struct FhDetector {
 	bool intTaps = false;   // the integral image holds int32 (GrayS32, from a GrayU8 frame) instead of float
 	std::vector<FhOctavePlan> plan;
 	int bitmapWords = 0;
-	DevBuf inten, expBuf, bitmap, prefix, cand, sorted, count;
+	DevBuf inten, expBuf, bitmap, prefix, cand, sorted, count, selKey, selIdx, selLevels;
+	bool nBest() const { return cfg.maxFeaturesPerScale > 0; }   // SelectNBestFeatures between the NMS and the scale-space test
 	std::vector<int> counts;   // per image, host
 	long long total = 0;
 
@@ -169,7 +170,6 @@ struct FhDetector {
 	int makePlan(bhip_ctx* ctx, int width, int height) {
 		plan.clear();
 		if (cfg.numberScalesPerOctave > BHIP_MAX_LEVELS || cfg.numberScalesPerOctave < 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "numberScalesPerOctave out of range");
-		if (cfg.maxFeaturesPerScale > 0) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "maxFeaturesPerScale > 0 (QuickSelect order unpinned): use the Java path");
 		if (cfg.extractRadius < 1) return bhip_fail(ctx, BHIP_ERR_INVALID, "Search radius must be >= 1");
 		if (cfg.initialSampleSize < 1 || cfg.initialSize < 3) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sample size / initial size");
 		if (width >= 32768 || height >= 32768) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "image too large for Point2D_I16");
@@ -216,12 +216,14 @@ struct FhDetector {
 	// Which octaves run fused, and which levels are copied from the octave below instead of being recomputed.  A box-filter response
 	// depends on (pixel, kernel size) only, and the default schedule repeats sizes: 15,27 | 27,51 | 51,99 are levels 1,3 of one octave and
 	// levels 0,1 of the next, on a lattice twice as coarse.  Sharing is enabled where the unrolled inner form and the clamped border
-	// form of the reference provably coincide (size = 3*blockSmall, odd), between a producer that keeps or exports its intensity and a
-	// stand-alone consumer.
+	// form of the reference cover the same boxes (size = 3*blockSmall, odd), between a producer that keeps or exports its intensity and a
+	// stand-alone consumer.  The two forms still round Dyy differently, and which pixels are "inner" depends on the step, so the
+	// consumer (k_hessian) copies a pixel only when both octaves evaluate it with the same form and computes the rest itself.
 	void planExecution() {
 		for (auto& o : plan) {
 			int ftx, fty, flds;
-			o.fused = !unfusedOnly() && !o.mids.empty() && bhip_fused_plan(o.skip, o.nlevels, o.sizes, cfg.extractRadius, &ftx, &fty, &flds);
+			// N-best selection needs every level's NMS list and intensity images in memory: stand-alone kernels
+			o.fused = !unfusedOnly() && !nBest() && !o.mids.empty() && bhip_fused_plan(o.skip, o.nlevels, o.sizes, cfg.extractRadius, &ftx, &fty, &flds);
 			o.fixed = o.fused && bhip_fused_is_fixed(o.skip, o.nlevels, o.sizes, cfg.extractRadius);
 			if (intTaps && !o.fixed) o.fused = false;   // integer taps: compile-time-geometry fused kernel or the stand-alone kernels
 			o.nexport = 0;
@@ -280,6 +282,13 @@ struct FhDetector {
 		BHIP_TRY(cand.reserve(ctx, (size_t)cap * sizeof(KeyPoint) * batch));
 		BHIP_TRY(sorted.reserve(ctx, (size_t)cap * sizeof(KeyPoint) * batch));
 		BHIP_TRY(count.reserve(ctx, (size_t)batch * 4 * 2));
+		if (nBest()) {
+			size_t nlv = 0;
+			for (auto& o : plan) nlv += o.mids.size();
+			BHIP_TRY(selKey.reserve(ctx, (size_t)cap * 4 * batch));
+			BHIP_TRY(selIdx.reserve(ctx, (size_t)cap * 4 * batch));
+			BHIP_TRY(selLevels.reserve(ctx, std::max<size_t>(nlv, 1) * 4 * 2 * batch));
+		}
 		return BHIP_OK;
 	}
 
@@ -322,7 +331,7 @@ struct FhDetector {
 				for (auto& m : o.mids) {
 					BHIP_TRY(bhip_launch_nms_scalespace(ctx, base + (m.level - 1) * levelStride, base + m.level * levelStride, base + (m.level + 1) * levelStride,
 														imageStride, o.w, batch, m.p, cfg.extractRadius, cfg.detectThreshold, bitmap.as<unsigned int>(),
-														bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap));
+														bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap, nBest()));
 				}
 			}
 			BHIP_TRY(bhip_launch_word_prefix(ctx, bitmap.as<unsigned int>(), bitmapWords, batch, prefix.as<unsigned int>(), count.as<int>() + batch));
@@ -341,6 +350,7 @@ struct FhDetector {
 			if (maxCount <= cap) {
 				BHIP_TRY(bhip_launch_rank_scatter(ctx, bitmap.as<unsigned int>(), bitmapWords, prefix.as<unsigned int>(), cand.as<KeyPoint>(), count.as<int>(),
 												  cap, batch, sorted.as<KeyPoint>()));
+				if (nBest()) BHIP_TRY(selectNBest(ctx));
 				return BHIP_OK;
 			}
 			// candidate list overflowed: grow and run the detector again
@@ -349,7 +359,36 @@ struct FhDetector {
 		}
 		return bhip_fail(ctx, BHIP_ERR_CAPACITY, "key point list kept overflowing");
 	}
-	void release() { inten.release(); expBuf.release(); bitmap.release(); prefix.release(); cand.release(); sorted.release(); count.release(); }
+	// maxFeaturesPerScale > 0: `sorted` holds every level's NMS maxima (ranked, with intensities).  Per level: select, scale-space test,
+	// sub-pixel fit (k_select_nbest, results into `cand`), then the levels are packed back into `sorted` and the counts re-read.
+	int selectNBest(bhip_ctx* ctx) {
+		int nlv = 0;
+		for (auto& o : plan) nlv += (int)o.mids.size();
+		int* levelStart = selLevels.as<int>();
+		int* levelCount = levelStart + (size_t)std::max(nlv, 1) * batch;
+		int li = 0;
+		for (auto& o : plan) {
+			const long long levelStride = (long long)o.w * o.h;
+			const float* base = inten.as<float>() + o.intenOff;
+			for (auto& m : o.mids) {
+				BHIP_TRY(bhip_launch_select_nbest(ctx, base + (m.level - 1) * levelStride, base + m.level * levelStride, base + (m.level + 1) * levelStride,
+												  o.intenImageStride, o.w, batch, m.p, cfg.extractRadius, cfg.maxFeaturesPerScale, bitmap.as<unsigned int>(),
+												  prefix.as<unsigned int>(), bitmapWords, sorted.as<KeyPoint>(), cap, selKey.as<float>(), selIdx.as<int>(),
+												  cand.as<KeyPoint>(), levelStart, levelCount, li, nlv));
+				li++;
+			}
+		}
+		BHIP_TRY(bhip_launch_compact_levels(ctx, cand.as<KeyPoint>(), cap, levelStart, levelCount, nlv, batch, sorted.as<KeyPoint>(), count.as<int>()));
+		BHIP_HIP(ctx, hipMemcpyAsync(counts.data(), count.p, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+		BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		total = 0;
+		for (int c : counts) total += c;
+		return BHIP_OK;
+	}
+	void release() {
+		inten.release(); expBuf.release(); bitmap.release(); prefix.release(); cand.release(); sorted.release(); count.release();
+		selKey.release(); selIdx.release(); selLevels.release();
+	}
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -748,6 +787,37 @@ int bhip_nonmax_block_f32(bhip_ctx* ctx, const float* intensity, int start, int 
 		BHIP_HIP(ctx, hipMemcpyAsync(xy, sc->e.p, (size_t)ncopy * 4, hipMemcpyDeviceToHost, ctx->stream));
 		BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
+	return BHIP_OK;
+}
+
+int bhip_select_nbest_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, const int16_t* xy, int n, int target,
+						  int positive, int16_t* out_xy, int* out_n) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, intensity, stride, width, height);
+	if (n < 0 || !out_n || (n > 0 && (!xy || !out_xy))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad corner list");
+	for (int i = 0; i < n; i++)
+		if (xy[2 * i] < 0 || xy[2 * i] >= width || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= height)
+			return bhip_fail(ctx, BHIP_ERR_INVALID, "corner outside the intensity image");   // GrayF32.get would throw ImageAccessException
+	if (n <= target) {
+		// SelectNBestFeatures.java:54-60: already few enough, an unpruned copy in the original order
+		if (n > 0) memcpy(out_xy, xy, (size_t)n * 4);
+		*out_n = n;
+		return BHIP_OK;
+	}
+	*out_n = 0;
+	if (target <= 0) return BHIP_OK;   // n > target, nothing to keep (QuickSelect with k = 0 is never reached with a positive N in the reference)
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(uploadImage(ctx, sc->a, intensity, start, stride, width, height));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)n * 4));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)n * 4));
+	BHIP_TRY(sc->d.reserve(ctx, (size_t)n * 4));
+	BHIP_TRY(sc->e.reserve(ctx, (size_t)target * 4));
+	BHIP_HIP(ctx, hipMemcpyAsync(sc->b.p, xy, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_TRY(bhip_launch_select_nbest_xy(ctx, sc->a.as<float>(), width, sc->b.as<int16_t>(), n, target, positive != 0, sc->c.as<float>(), sc->d.as<int>(),
+										 sc->e.as<int16_t>()));
+	BHIP_HIP(ctx, hipMemcpyAsync(out_xy, sc->e.p, (size_t)target * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out_n = target;
 	return BHIP_OK;
 }
 

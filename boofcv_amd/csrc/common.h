@@ -168,7 +168,14 @@ struct DetectLevelParams {
 };
 int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
 							   DetectLevelParams p, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							   int cap);
+							   int cap, bool listOnly = false);
+int bhip_launch_select_nbest(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
+							 DetectLevelParams p, int radius, int target, const unsigned int* bitmap, const unsigned int* prefix, int bitmapWords,
+							 const KeyPoint* nms, int cap, float* keyBuf, int* idxBuf, KeyPoint* out, int* levelStart, int* levelCount, int levelIndex, int nlv);
+int bhip_launch_select_nbest_xy(bhip_ctx* ctx, const float* img, int stride, const int16_t* xy, int n, int target, bool positive, float* key, int* idx,
+								int16_t* out);
+int bhip_launch_compact_levels(bhip_ctx* ctx, const KeyPoint* src, int cap, const int* levelStart, const int* levelCount, int nlv, int batch, KeyPoint* dst,
+							   int* totals);
 int bhip_launch_rank_scatter(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, unsigned int* wordPrefix, const KeyPoint* cand,
 							 const int* candCount, int cap, int batch, KeyPoint* sorted);
 int bhip_launch_nonmax_only(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border, unsigned int* bitmap,

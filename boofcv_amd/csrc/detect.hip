@@ -52,6 +52,38 @@ __device__ __forceinline__ float polyPeak(float lower, float middle, float upper
 	return -b / (2.0f * a);
 }
 
+// FastHessianFeatureDetector.findLocalScaleSpaceMax :268-294 for one NMS maximum (x,y) of the middle level with value val: border guard,
+// checkMax on the lower and upper level, polyPeak fits.  Fills kp.x / kp.y / kp.scale and returns true when the point is a key point.
+__device__ __forceinline__ bool scaleSpaceKeyPoint(const float* __restrict__ lower, const float* __restrict__ mid, const float* __restrict__ upper, int stride,
+													const DetectLevelParams& p, int r, int x, int y, float val, KeyPoint& kp) {
+	const int w = p.w, h = p.h;
+	// candidates hugging the ignore border are dropped
+	const int ignoreR = p.border + r;
+	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) return false;
+	// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
+	bool below = true;
+#pragma unroll
+	for (int j = y - 1; j <= y + 1; j++)
+#pragma unroll
+		for (int i = x - 1; i <= x + 1; i++) {
+			const bool in = i >= 0 && i < w && j >= 0 && j < h;
+			const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
+			const float up = in ? upper[(long long)j * stride + i] : 0.0f;
+			if (lo >= val || up >= val) below = false;
+		}
+	if (!below) return false;
+	const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
+	const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
+	const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
+	const float interpX = ((float)x + peakX) * (float)p.skip;
+	const float interpY = ((float)y + peakY) * (float)p.skip;
+	const float interpS = (float)p.sizeMid + peakS * (float)(p.sizeMid - p.sizeLower);
+	kp.x = (double)interpX;
+	kp.y = (double)interpY;
+	kp.scale = 1.2 * (double)interpS / 9.0;
+	return true;
+}
+
 struct NmsParams {
 	const float* lower;
 	const float* mid;
@@ -66,6 +98,7 @@ struct NmsParams {
 	KeyPoint* cand;
 	int* candCount;
 	int cap;
+	int listOnly;
 };
 
 #define NMS_ROWS 4   // rows per thread: the column neighbours are shared and the grid has 4x fewer, longer-lived blocks
@@ -119,40 +152,16 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 		const float val = mid[(long long)y * stride + x];
 		if (!(r == 2 ? strictLocalMax<2>(mid, stride, w, h, x, y, r, val, P.threshold) : strictLocalMax<0>(mid, stride, w, h, x, y, r, val, P.threshold))) continue;
 
-		// findLocalScaleSpaceMax: candidates hugging the ignore border are dropped
-		const int ignoreR = b + r;
-		if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) continue;
-		const float* lower = P.lower + (long long)img * P.imageStride;
-		const float* upper = P.upper + (long long)img * P.imageStride;
-		// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
-		bool below = true;
-#pragma unroll
-		for (int j = y - 1; j <= y + 1; j++)
-#pragma unroll
-			for (int i = x - 1; i <= x + 1; i++) {
-				const bool in = i >= 0 && i < w && j >= 0 && j < h;
-				const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
-				const float up = in ? upper[(long long)j * stride + i] : 0.0f;
-				if (lo >= val || up >= val) below = false;
-			}
-		if (!below) continue;
-		const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
-		const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
-		const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
-		const float interpX = ((float)x + peakX) * (float)P.p.skip;
-		const float interpY = ((float)y + peakY) * (float)P.p.skip;
-		const float interpS = (float)P.p.sizeMid + peakS * (float)(P.p.sizeMid - P.p.sizeLower);
-		const double scale = 1.2 * (double)interpS / 9.0;
-
 		const int step = r + 1;
 		const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
+		KeyPoint kp;
+		if (P.listOnly) {
+			// maxFeaturesPerScale > 0: every NMS maximum is listed with its intensity; selection and the scale-space test follow in k_select_nbest
+			kp.x = (double)x; kp.y = (double)y; kp.scale = (double)val;
+		} else if (!scaleSpaceKeyPoint(P.lower + (long long)img * P.imageStride, mid, P.upper + (long long)img * P.imageStride, stride, P.p, r, x, y, val, kp)) continue;
 		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
 		const int slot = atomicAdd(&P.candCount[img], 1);
 		if (slot < P.cap) {
-			KeyPoint kp;
-			kp.x = (double)interpX;
-			kp.y = (double)interpY;
-			kp.scale = scale;
 			kp.key = bit;
 			kp.pad = 0;
 			P.cand[(long long)img * P.cap + slot] = kp;
@@ -162,10 +171,10 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 
 int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
 							   DetectLevelParams p, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							   int cap) {
+							   int cap, bool listOnly) {
 	const int rw = p.w - 2 * p.border, rh = p.h - 2 * p.border;
 	if (rw <= 0 || rh <= 0) return BHIP_OK;
-	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap};
+	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap, listOnly ? 1 : 0};
 	dim3 grid((rw + 255) / 256, (rh + NMS_ROWS - 1) / NMS_ROWS, batch);
 	{
 		ProfScope ps(ctx, "k_nms_scalespace", 4.0 * p.w * p.h * batch);  // the mid level read once
@@ -240,6 +249,195 @@ int bhip_launch_rank_scatter(bhip_ctx* ctx, const unsigned int* bitmap, int bitm
 		ProfScope ps(ctx, "k_rank_scatter");
 		hipLaunchKernelGGL(k_rank_scatter, grid, dim3(256), 0, ctx->stream, bitmap, bitmapWords, (const unsigned int*)wordPrefix, cand, candCount, cap, sorted);
 	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// maxFeaturesPerScale > 0   (FastHessianFeatureDetector.java:255-262 -> SelectNBestFeatures.process :51-93)
+//
+// The NMS maxima of every middle level have been listed in block-raster order with their intensities (k_nms_scalespace in listOnly mode
+// + the popcount ranking).  One wave per (image, level):
+//   1. n <= N: the list is kept as it is.  Otherwise keys = -intensity and QuickSelect.selectIndex(keys, N, n, indexes) is run by lane 0
+//      exactly as the sequential routine runs (ddogleg's routine = Numerical Recipes `select` with an index array; see the oracle's
+//      quickSelectIndex -- the exchange sequence decides the output order and which of several equal keys survive, so it is not parallelised);
+//   2. the first min(n, N) entries, in that order, go through the border guard, the 3x3x3 scale-space test and the sub-pixel fit, 64 at a
+//      time, and the survivors are appended in order (ballot + popcount).
+// The results of a level are written at the level's own offset in the NMS list (they are never more than the list itself), then
+// k_compact_levels closes the gaps.
+// ---------------------------------------------------------------------------------------------------------------
+#define SEL_LDS 4096   // lists up to this long are selected in LDS, longer ones in their global scratch
+
+struct SelectParams {
+	const float* lower;
+	const float* mid;
+	const float* upper;
+	long long imageStride;
+	int stride;
+	DetectLevelParams p;
+	int radius;
+	int target;
+	const unsigned int* bitmap;
+	const unsigned int* prefix;
+	int bitmapWords;
+	const KeyPoint* nms;   // [image][cap] ranked NMS maxima: x, y = pixel, scale = intensity
+	int cap;
+	float* keyBuf;         // [image][cap]
+	int* idxBuf;           // [image][cap]
+	KeyPoint* out;         // [image][cap]
+	int* levelStart;       // [image][nlv]
+	int* levelCount;       // [image][nlv]
+	int levelIndex, nlv;
+};
+
+__device__ __forceinline__ int bitRank(const unsigned int* __restrict__ bm, const unsigned int* __restrict__ pf, unsigned int bit) {
+	return (int)(pf[bit >> 5] + __popc(bm[bit >> 5] & ((1u << (bit & 31)) - 1u)));
+}
+
+__device__ void quickSelectIndexSeq(float* data, int k, int n, int* indexes) {
+	int l = 0, ir = n - 1;
+#define QS_SWAP(a_, b_) do { const float tf = data[a_]; data[a_] = data[b_]; data[b_] = tf; const int ti = indexes[a_]; indexes[a_] = indexes[b_]; indexes[b_] = ti; } while (0)
+	for (;;) {
+		if (ir <= l + 1) {
+			if (ir == l + 1 && data[ir] < data[l]) QS_SWAP(l, ir);
+			return;
+		}
+		const int mid = (l + ir) >> 1, lp1 = l + 1;
+		QS_SWAP(mid, lp1);
+		if (data[l] > data[ir]) QS_SWAP(l, ir);
+		if (data[lp1] > data[ir]) QS_SWAP(lp1, ir);
+		if (data[l] > data[lp1]) QS_SWAP(l, lp1);
+		int i = lp1, j = ir;
+		const float a = data[lp1];
+		const int indexA = indexes[lp1];
+		for (;;) {
+			do i++; while (data[i] < a);   // data[ir] >= a and data[l] <= a are the sentinels, as in the sequential routine
+			do j--; while (data[j] > a);
+			if (j < i) break;
+			QS_SWAP(i, j);
+		}
+		data[lp1] = data[j]; data[j] = a;
+		indexes[lp1] = indexes[j]; indexes[j] = indexA;
+		if (j >= k) ir = j - 1;
+		if (j <= k) l = i;
+	}
+#undef QS_SWAP
+}
+
+__global__ __launch_bounds__(64) void k_select_nbest(SelectParams P) {
+	__shared__ float ldsKey[SEL_LDS];
+	__shared__ int ldsIdx[SEL_LDS];
+	const int img = blockIdx.x;
+	const int lane = threadIdx.x;
+	const unsigned int* bm = P.bitmap + (long long)img * P.bitmapWords;
+	const unsigned int* pf = P.prefix + (long long)img * P.bitmapWords;
+	const int start = bitRank(bm, pf, P.p.bitBase);
+	const int end = bitRank(bm, pf, P.p.bitBase + (unsigned)P.p.nbx * (unsigned)P.p.nby);
+	const int n = end - start;
+	const KeyPoint* list = P.nms + (long long)img * P.cap + start;
+	KeyPoint* out = P.out + (long long)img * P.cap + start;
+	const bool select = n > P.target;
+	const int m = select ? P.target : n;
+	const bool inLds = n <= SEL_LDS;
+	float* key = inLds ? ldsKey : P.keyBuf + (long long)img * P.cap + start;
+	int* idx = inLds ? ldsIdx : P.idxBuf + (long long)img * P.cap + start;
+	if (select) {
+		for (int i = lane; i < n; i += 64) {
+			key[i] = -(float)list[i].scale;   // intensity was widened from float: exact
+			idx[i] = i;
+		}
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) quickSelectIndexSeq(key, P.target, n, idx);
+		__threadfence_block();
+		__builtin_amdgcn_wave_barrier();
+	}
+	const float* lower = P.lower + (long long)img * P.imageStride;
+	const float* mid = P.mid + (long long)img * P.imageStride;
+	const float* upper = P.upper + (long long)img * P.imageStride;
+	int base = 0;
+	for (int j0 = 0; j0 < m; j0 += 64) {
+		const int j = j0 + lane;
+		bool ok = false;
+		KeyPoint kp;
+		kp.x = kp.y = kp.scale = 0; kp.key = 0; kp.pad = 0;
+		if (j < m) {
+			const KeyPoint src = list[select ? idx[j] : j];
+			const int x = (int)src.x, y = (int)src.y;
+			ok = scaleSpaceKeyPoint(lower, mid, upper, P.stride, P.p, P.radius, x, y, (float)src.scale, kp);
+		}
+		const unsigned long long vote = __ballot(ok);
+		if (ok) out[base + __popcll(vote & ((1ull << lane) - 1ull))] = kp;
+		base += __popcll(vote);
+	}
+	if (lane == 0) {
+		P.levelStart[(long long)img * P.nlv + P.levelIndex] = start;
+		P.levelCount[(long long)img * P.nlv + P.levelIndex] = base;
+	}
+}
+
+// one wave per image: the per-level results, in level order, are packed into `dst` and the image's key point count is written
+__global__ __launch_bounds__(64) void k_compact_levels(const KeyPoint* __restrict__ src, int cap, const int* __restrict__ levelStart, const int* __restrict__ levelCount,
+														int nlv, KeyPoint* __restrict__ dst, int* __restrict__ totals) {
+	const int img = blockIdx.x, lane = threadIdx.x;
+	int off = 0;
+	for (int l = 0; l < nlv; l++) {
+		const int s = levelStart[(long long)img * nlv + l], c = levelCount[(long long)img * nlv + l];
+		for (int i = lane; i < c; i += 64) dst[(long long)img * cap + off + i] = src[(long long)img * cap + s + i];
+		off += c;
+	}
+	if (lane == 0) totals[img] = off;
+}
+
+int bhip_launch_select_nbest(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
+							 DetectLevelParams p, int radius, int target, const unsigned int* bitmap, const unsigned int* prefix, int bitmapWords,
+							 const KeyPoint* nms, int cap, float* keyBuf, int* idxBuf, KeyPoint* out, int* levelStart, int* levelCount, int levelIndex, int nlv) {
+	if (batch <= 0) return BHIP_OK;
+	SelectParams P{lower, mid, upper, imageStride, stride, p, radius, target, bitmap, prefix, bitmapWords, nms, cap, keyBuf, idxBuf, out, levelStart, levelCount,
+				   levelIndex, nlv};
+	{
+		ProfScope ps(ctx, "k_select_nbest");
+		hipLaunchKernelGGL(k_select_nbest, dim3(batch), dim3(64), 0, ctx->stream, P);
+	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+int bhip_launch_compact_levels(bhip_ctx* ctx, const KeyPoint* src, int cap, const int* levelStart, const int* levelCount, int nlv, int batch, KeyPoint* dst,
+							   int* totals) {
+	if (batch <= 0) return BHIP_OK;
+	{
+		ProfScope ps(ctx, "k_compact_levels");
+		hipLaunchKernelGGL(k_compact_levels, dim3(batch), dim3(64), 0, ctx->stream, src, cap, levelStart, levelCount, nlv, dst, totals);
+	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// stand-alone SelectNBestFeatures.process(intensity, corners, positive) for n > target: one wave; keys = -/+ intensity(x,y), the
+// sequential QuickSelect, then the first `target` points in index order
+__global__ __launch_bounds__(64) void k_select_nbest_xy(const float* __restrict__ img, int stride, const int16_t* __restrict__ xy, int n, int target, int positive,
+														 float* key, int* idx, int16_t* __restrict__ out) {
+	const int lane = threadIdx.x;
+	for (int i = lane; i < n; i += 64) {
+		const float v = img[(long long)xy[2 * i + 1] * stride + xy[2 * i]];
+		key[i] = positive ? -v : v;
+		idx[i] = i;
+	}
+	__threadfence_block();
+	__builtin_amdgcn_wave_barrier();
+	if (lane == 0) quickSelectIndexSeq(key, target, n, idx);
+	__threadfence_block();
+	__builtin_amdgcn_wave_barrier();
+	for (int i = lane; i < target; i += 64) {
+		out[2 * i] = xy[2 * idx[i]];
+		out[2 * i + 1] = xy[2 * idx[i] + 1];
+	}
+}
+
+int bhip_launch_select_nbest_xy(bhip_ctx* ctx, const float* img, int stride, const int16_t* xy, int n, int target, bool positive, float* key, int* idx,
+								int16_t* out) {
+	hipLaunchKernelGGL(k_select_nbest_xy, dim3(1), dim3(64), 0, ctx->stream, img, stride, xy, n, target, positive ? 1 : 0, key, idx, out);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

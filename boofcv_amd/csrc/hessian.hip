@@ -27,6 +27,8 @@ struct HessParams {
 	int outStride;
 	HessLevel lv[BHIP_MAX_LEVELS];
 	HessLevelSource from[BHIP_MAX_LEVELS];
+	int srcBorder[BHIP_MAX_LEVELS];   // shared levels: the producing octave's (step skip/2) inner-region border, width and height
+	int srcW, srcH;
 };
 
 // T = float (GrayF32 integral image) or int (GrayS32: exact integer box sums, converted where the reference converts -- at the
@@ -56,20 +58,28 @@ __global__ __launch_bounds__(256) void k_hessian(HessParams P) {
 	const int img = blockIdx.z / P.nlevels;
 	const int level = blockIdx.z - img * P.nlevels;
 	if (x >= P.w) return;
-	if (P.from[level].src) {
-		// same kernel size one octave down: the intensity of a pixel does not depend on the sampling step
-		const HessLevelSource S = P.from[level];
-		P.out[(long long)img * P.imageStrideOut + (long long)level * P.levelStride + (long long)y * P.outStride + x] =
-			S.src[(long long)img * S.imageStride + (long long)(y * S.step) * S.stride + x * S.step];
-		return;
-	}
 	const HessLevel L = P.lv[level];
+	const bool inner = x >= L.border && x < P.w - L.border && y >= L.border && y < P.h - L.border;
+	if (P.from[level].src) {
+		// Same kernel size one octave down.  A response depends on the pixel and the kernel size, and on which of the reference's two
+		// forms evaluates it: hessianInner sums the Dyy boxes as ((br - bl) - tr) + tl, the border form (block_zero) as ((br - tr) - bl) + tl,
+		// so the two can differ in the last bit.  The inner regions of the two octaves are not the same set of pixels (borderOrig depends
+		// on the step), hence: copy where both octaves use the same form, compute in place on the few rows / columns where they do not.
+		const int bp = P.srcBorder[level];
+		const int px = 2 * x, py = 2 * y;
+		const bool srcInner = px >= bp && px < P.srcW - bp && py >= bp && py < P.srcH - bp;
+		if (srcInner == inner) {
+			const HessLevelSource S = P.from[level];
+			P.out[(long long)img * P.imageStrideOut + (long long)level * P.levelStride + (long long)y * P.outStride + x] =
+				S.src[(long long)img * S.imageStride + (long long)(y * S.step) * S.stride + x * S.step];
+			return;
+		}
+	}
 	const T* __restrict__ d = (const T*)P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride;
 	const int skip = P.skip;
 	const int xx = x * skip, yy = y * skip;
 	float Dxx, Dyy, Dxy;
-	const bool inner = x >= L.border && x < P.w - L.border && y >= L.border && y < P.h - L.border;
 	if (inner) {
 		// hessianInner: the first inner column sits at offset `lost`, then +skip per output pixel
 		const int col = L.lost + (x - L.border) * skip;
@@ -155,7 +165,14 @@ int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlev
 	for (int i = 0; i < nlevels; i++) {
 		P.lv[i] = makeLevel(sizes[i], skip);
 		P.from[i] = from ? from[i] : HessLevelSource{nullptr, 0, 0, 1};
+		P.srcBorder[i] = 0;
+		if (P.from[i].src) {
+			if (skip % 2 != 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "a shared level needs an octave at half the step");
+			P.srcBorder[i] = makeLevel(sizes[i], skip / 2).border;
+		}
 	}
+	P.srcW = skip >= 2 ? ii.width / (skip / 2) : 0;
+	P.srcH = skip >= 2 ? ii.height / (skip / 2) : 0;
 	if (P.w <= 0 || P.h <= 0) return BHIP_OK;
 	dim3 grid((P.w + 255) / 256, P.h, batch * nlevels);
 	{

@@ -48,7 +48,7 @@ typedef struct bhip_surf bhip_surf;
 typedef struct {
 	float detectThreshold;     /* 1 */
 	int extractRadius;         /* 2 */
-	int maxFeaturesPerScale;   /* -1 (>0 is BHIP_ERR_UNSUPPORTED: ddogleg QuickSelect order is unpinned) */
+	int maxFeaturesPerScale;   /* -1; > 0: SelectNBestFeatures per level (order = the restated ddogleg QuickSelect, unpinned vs the real jar) */
 	int initialSampleSize;     /* 1 */
 	int initialSize;           /* 9 */
 	int numberScalesPerOctave; /* 4 */
@@ -149,6 +149,14 @@ int bhip_hessian_f32(bhip_ctx* ctx, const float* ii, int iiStart, int iiStride, 
  * Writes up to cap (x,y) int16 pairs in block-raster order (the USE_CONCURRENT=false order); *n is the number found. */
 int bhip_nonmax_block_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, int radius, float threshold,
 						  int border, int16_t* xy, int cap, int* n);
+/* SelectNBestFeatures.process(intensity, corners, positive) + getBestCorners() (F:alg/feature/detect/extract/SelectNBestFeatures.java:51-97):
+ * n <= target copies the list; otherwise keys = -intensity (positive) or +intensity and org.ddogleg.sorting.QuickSelect.selectIndex(keys,
+ * target, n, indexes) decides which `target` corners are kept and in which order.  ddogleg is not part of the reference tree: the routine
+ * is the published Numerical Recipes `select` with an index array (see oracle/boof_oracle.hpp quickSelectIndex); the kept SET is pinned
+ * (the N most intense, exact ties at the cut aside), the order is "parity unpinned".  xy / out_xy: (x,y) int16 pairs; out_xy holds
+ * min(n, target) pairs.  Used by FastHessianFeatureDetector (maxFeaturesPerScale > 0) and GeneralFeatureDetector (maxFeatures > 0). */
+int bhip_select_nbest_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, const int16_t* xy, int n, int target,
+						  int positive, int16_t* out_xy, int* out_n);
 /* FastHessianFeatureDetector.detect(ii) (F:alg/feature/detect/interest/FastHessianFeatureDetector.java:156-188) on a host integral image */
 int bhip_fh_detect_f32(bhip_ctx* ctx, const bhip_fh_cfg* cfg, const float* ii, int iiStart, int iiStride, int width, int height, double* xy_scale,
 					   int cap, int* n);

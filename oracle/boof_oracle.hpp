@@ -553,14 +553,50 @@ struct FastHessianFeatureDetector {
 			}
 		}
 	}
-	// F:alg/feature/detect/extract/SelectNBestFeatures.java:51-93.  ddogleg QuickSelect's output order is not
-	// specified (order unpinned); here: N largest, descending intensity, ties by original index.
-	static void selectNBest(const GrayF32& inten, const QueueCorner& orig, int target, QueueCorner& best) {
+	// org.ddogleg.sorting.QuickSelect.selectIndex(float[] data, int k, int maxIndex, int[] indexes) -- ddogleg is not in the reference
+	// tree.  Its documentation names its source: the `select` routine of Numerical Recipes (3rd ed., 8.5) with an index array
+	// carried through every exchange; that published routine is restated here.  Median-of-three with the median parked at l+1, Hoare
+	// partition, iterate on the side holding k.  On return indexes[0..k) are the k smallest keys (in the partially sorted order the
+	// exchanges leave them) and `data` is permuted the same way.  PARITY UNPINNED against the real ddogleg build: the only pin the
+	// reference holds is TestSelectNBestFeatures.java:36-68 (the single best comes first for k = 3 of 4), which this order satisfies.
+	static void quickSelectIndex(float* data, int k, int maxIndex, int* indexes) {
+		int l = 0, ir = maxIndex - 1;
+		for (int i = 0; i < maxIndex; i++) indexes[i] = i;
+		auto swp = [&](int a, int b) { std::swap(data[a], data[b]); std::swap(indexes[a], indexes[b]); };
+		for (;;) {
+			if (ir <= l + 1) {
+				if (ir == l + 1 && data[ir] < data[l]) swp(l, ir);
+				return;
+			}
+			const int mid = (l + ir) >> 1, lp1 = l + 1;
+			swp(mid, lp1);
+			if (data[l] > data[ir]) swp(l, ir);
+			if (data[lp1] > data[ir]) swp(lp1, ir);
+			if (data[l] > data[lp1]) swp(l, lp1);
+			int i = lp1, j = ir;
+			const float a = data[lp1];
+			const int indexA = indexes[lp1];
+			for (;;) {
+				do i++; while (data[i] < a);
+				do j--; while (data[j] > a);
+				if (j < i) break;
+				swp(i, j);
+			}
+			data[lp1] = data[j]; data[j] = a;
+			indexes[lp1] = indexes[j]; indexes[j] = indexA;
+			if (j >= k) ir = j - 1;
+			if (j <= k) l = i;
+		}
+	}
+	// F:alg/feature/detect/extract/SelectNBestFeatures.java:51-93 (positive = true as FastHessianFeatureDetector.java:257 calls it;
+	// positive = false keeps the smallest): keys are -intensity so the k smallest keys are the k largest intensities.
+	static void selectNBest(const GrayF32& inten, const QueueCorner& orig, int target, QueueCorner& best, bool positive = true) {
 		best.clear();
 		if ((int)orig.size() <= target) { best = orig; return; }
 		std::vector<int> idx(orig.size());
-		for (size_t i = 0; i < idx.size(); i++) idx[i] = (int)i;
-		std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return inten.get(orig[a].x, orig[a].y) > inten.get(orig[b].x, orig[b].y); });
+		std::vector<float> key(orig.size());
+		for (size_t i = 0; i < idx.size(); i++) key[i] = positive ? -inten.get(orig[i].x, orig[i].y) : inten.get(orig[i].x, orig[i].y);
+		quickSelectIndex(key.data(), target, (int)orig.size(), idx.data());
 		for (int i = 0; i < target; i++) best.push_back(orig[idx[i]]);
 	}
 };

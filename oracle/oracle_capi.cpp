@@ -117,6 +117,15 @@ int orc_nonmax(const orc_image* intensity, int radius, float threshold, int bord
 	return n;
 }
 
+// ---- SelectNBestFeatures.process(intensity, corners, positive): out_xy gets min(n, target) points in the reference's output order ----
+int orc_select_nbest(const orc_image* intensity, const int16_t* xy, int n, int target, int positive, int16_t* out_xy) {
+	QueueCorner q, best;
+	for (int i = 0; i < n; i++) q.push_back(Point2D_I16{xy[2 * i], xy[2 * i + 1]});
+	FastHessianFeatureDetector::selectNBest(view(intensity), q, target, best, positive != 0);
+	for (size_t i = 0; i < best.size(); i++) { out_xy[2 * i] = best[i].x; out_xy[2 * i + 1] = best[i].y; }
+	return (int)best.size();
+}
+
 // ---- fast hessian detector on an integral image ----
 int orc_fh_detect(const orc_image* ii, const orc_fh_cfg* cfg, double* out_xys, int cap, int threads) {
 	FastHessianFeatureDetector det(toFh(cfg));

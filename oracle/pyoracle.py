@@ -89,6 +89,7 @@ def lib():
             "orc_hessian": (None, [IM, C.c_int, C.c_int, IM, C.c_int, C.c_int]),
             "orc_nonmax": (C.c_int, [IM, C.c_int, C.c_float, C.c_int, C.c_int, P(C.c_int16), C.c_int, C.c_int]),
             "orc_fh_detect": (C.c_int, [IM, P(FhCfg), P(C.c_double), C.c_int, C.c_int]),
+            "orc_select_nbest": (C.c_int, [IM, P(C.c_int16), C.c_int, C.c_int, C.c_int, P(C.c_int16)]),
             "orc_orientation": (C.c_double, [IM, C.c_int, P(OriCfg), C.c_double, C.c_double, C.c_double]),
             "orc_sparse_gradient": (C.c_int, [IM, C.c_double, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
             "orc_describe": (None, [IM, C.c_int, P(SurfCfg), C.c_double, C.c_double, C.c_double, C.c_double, P(C.c_double), P(C.c_uint8), C.c_int]),
@@ -239,6 +240,14 @@ def nonmax(intensity, radius, threshold, border, naive=False, threads=1):
     cap = intensity.width * intensity.height
     out = np.zeros((cap, 2), dtype=np.int16)
     n = lib().orc_nonmax(intensity.c(), radius, threshold, border, 1 if naive else 0, _fp(out, C.c_int16), cap, threads)
+    return out[:n].copy()
+
+
+def select_nbest(intensity, corners, target, positive=True):
+    """SelectNBestFeatures.process: corners = (n,2) int16 (x,y); returns the kept points in the reference's output order."""
+    xy = np.ascontiguousarray(corners, dtype=np.int16).reshape(-1, 2)
+    out = np.zeros((max(len(xy), 1), 2), dtype=np.int16)
+    n = lib().orc_select_nbest(intensity.c(), _fp(xy, C.c_int16), len(xy), target, 1 if positive else 0, _fp(out, C.c_int16))
     return out[:n].copy()
 
 

@@ -1,0 +1,21 @@
+# dynamic instruction mix per own kernel (rocprofv3 PMC, SQ counters), batch 32
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmc_insts && mkdir -p gpurun_out/pmc_insts
+echo "pmc insts: $(date +%T)"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_insts -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --batch 32 > gpurun_out/pmc_insts/run.log 2>&1
+python3 - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob('gpurun_out/pmc_insts/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if not (k.startswith('k_') or k.startswith('void k_')):
+            continue
+        agg[k.split('(')[0].replace('void ', '')[:48]][r['Counter_Name']] += float(r['Counter_Value'])
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
+    w = max(v.get('SQ_WAVES', 1), 1)
+    print('%-50s waves %9d  per wave: VALU %7.0f SALU %6.0f LDS %6.0f VMEMrd %5.0f VMEMwr %4.0f SMEM %4.0f  wave-cycles(x4) %8.0f' % (
+        k, w, v.get('SQ_INSTS_VALU', 0) / w, v.get('SQ_INSTS_SALU', 0) / w, v.get('SQ_INSTS_LDS', 0) / w, v.get('SQ_INSTS_VMEM_RD', 0) / w,
+        v.get('SQ_INSTS_VMEM_WR', 0) / w, v.get('SQ_INSTS_SMEM', 0) / w, 4 * v.get('SQ_WAVE_CYCLES', 0) / w))
+PY
+find gpurun_out/pmc_insts -name "*.csv" -size +2M -delete

@@ -117,7 +117,8 @@ def test_nonmax_rejects_unsupported_config(api):
 
 
 # ------------------------------------------------------------------------------------------------------------------ detector
-@pytest.mark.parametrize("w,h,seed", [(80, 90, 1), (100, 120, 234), (400, 300, 234), (640, 480, 234), (57, 301, 7)])
+@pytest.mark.parametrize("w,h,seed", [(80, 90, 1), (100, 120, 234), (400, 300, 234), (640, 480, 234), (57, 301, 7), (400, 300, 6), (402, 302, 6),
+                                      (403, 301, 8), (1001, 703, 9), (1918, 1078, 10)])
 def test_fast_hessian_points_bit_exact(api, orc, w, h, seed):
     ii = orc.integral(orc.noise_image(w, h, seed))
     exp = orc.fh_detect(ii)
@@ -135,8 +136,34 @@ def test_fast_hessian_config_variants(api, orc):
         det = api.FastHessianFeatureDetector(api.ConfigFastHessian(**cfg))
         det.detect(G(api, ii))
         assert np.array_equal(det.getFoundPoints(), exp), cfg
-    with pytest.raises(RuntimeError):
-        d = api.FastHessianFeatureDetector(api.ConfigFastHessian(maxFeaturesPerScale=10)); d.detect(G(api, ii))
+
+
+@pytest.mark.parametrize("w,h,seed,nbest", [(300, 260, 21, 10), (300, 260, 21, 1), (640, 480, 234, 100), (400, 300, 5, 100000), (402, 301, 8, 100000),
+                                            (407, 303, 9, 100000), (1920, 1080, 7, 300)])
+def test_fast_hessian_max_features_per_scale(api, orc, w, h, seed, nbest):
+    """SelectNBestFeatures between the NMS and the scale-space test (FastHessianFeatureDetector.java:255-262).  The GPU runs the
+    same sequential QuickSelect exchange sequence as the oracle, so order and tie survivors agree bit for bit; against the real ddogleg
+    build the order is unpinned (the library is not in the reference tree), the kept *set* is not."""
+    img = orc.noise_image(w, h, seed)
+    ii = orc.integral(img)
+    exp = orc.fh_detect(ii, orc.FhCfg(maxFeaturesPerScale=nbest), threads=8)
+    det = api.FastHessianFeatureDetector(api.ConfigFastHessian(maxFeaturesPerScale=nbest))
+    det.detect(G(api, ii))
+    got = det.getFoundPoints()
+    assert len(exp) > 0 and got.shape == exp.shape and np.array_equal(got, exp)
+    full = orc.fh_detect(ii, threads=8)
+    assert {tuple(p) for p in got.tolist()} <= {tuple(p) for p in full.tolist()}
+    if nbest >= 100000:
+        assert np.array_equal(got, full)   # N above every list length: nothing is pruned, original order
+    # detect + describe with the limit, batched (two different frames): same key points per frame, descriptors within tolerance
+    if w <= 640:
+        cfg = api.ConfigFastHessian(maxFeaturesPerScale=nbest)
+        dd = api.FactoryDetectDescribe.surfStable(cfg, None, None, api.GrayF32)
+        ref = orc.Surf(True, fh=orc.FhCfg(maxFeaturesPerScale=nbest))
+        img2 = orc.noise_image(w, h, seed + 1)
+        dd.detectBatch([G(api, img), G(api, img2)])
+        for k, im in enumerate((img, img2)):
+            _compare_surf(api, orc, dd, ref, im, k)
 
 
 def test_fast_hessian_image_smaller_than_kernel(api, orc):
@@ -682,12 +709,14 @@ def test_orientation_degenerate_regimes(api, orc):
     assert np.array_equal(ang, rang) and np.array_equal(desc, rdesc) and np.all(desc == 0)
 
 
-def test_detector_plans_agree(api, orc, tmp_path):
+@pytest.mark.parametrize("w,h,seed,hi", [(700, 520, 21, 255), (400, 300, 6, 100), (403, 301, 8, 100)])
+def test_detector_plans_agree(api, orc, tmp_path, w, h, seed, hi):
     """The detector has three execution plans that must give the same key points bit for bit: fused octaves + levels shared between
     octaves (default), no sharing (BHIP_DETECT_NOSHARE=1), and the stand-alone kernels for every octave (BHIP_DETECT_UNFUSED=1, with
     and without sharing).  The switches are read once per process, so the variants run in child processes."""
     import os, subprocess, sys
-    img = orc.noise_image(700, 520, 21, 0, 255)
+    # (400, 300, 6): a key point next to the column where octave 1 evaluates size 27 with the border form and octave 0 with the inner form
+    img = orc.noise_image(w, h, seed, 0, hi)
     np.save(tmp_path / "img.npy", img.array())
     fh = api.FastHessianFeatureDetector(api.ConfigFastHessian(1, 2, -1, 1, 9, 4, 4))
     ii = api.IntegralImageOps.transform(G(api, img))
@@ -736,6 +765,25 @@ def test_surf_color_planar_parity(api, orc, stable):
         api.FactoryDetectDescribe.surfColorStable(None, None, None, api.GrayF32)
 
 
+def test_select_nbest_reference_literals(api):  # FT:alg/feature/detect/extract/TestSelectNBestFeatures.java:36-93
+    a = np.zeros((20, 10), np.float32)
+    a[10, 5] = -3; a[10, 4] = -3.5; a[11, 5] = 0; a[8, 8] = 10
+    corners = [api.Point2D_I16(5, 10), api.Point2D_I16(4, 10), api.Point2D_I16(5, 11), api.Point2D_I16(8, 8)]
+    alg = api.SelectNBestFeatures(20)
+    alg.setN(3)
+    alg.process(api.GrayF32.wrap(a), corners, True)
+    found = alg.getBestCorners()
+    assert len(found) == 3 and (found[0].x, found[0].y) == (8, 8)
+    alg.process(api.GrayF32.wrap(a), corners, False)
+    found = alg.getBestCorners()
+    assert len(found) == 3 and (found[0].x, found[0].y) == (4, 10)
+    alg.setN(20)   # testTooLittle: fewer corners than N, all are returned
+    alg.process(api.GrayF32.wrap(a), corners, True)
+    assert [(p.x, p.y) for p in alg.getBestCorners()] == [(5, 10), (4, 10), (5, 11), (8, 8)]
+    with pytest.raises(api.IllegalArgumentException):
+        alg.process(api.GrayF32.wrap(a), [api.Point2D_I16(10, 3)], True)   # outside the image
+
+
 @pytest.mark.parametrize("w,h", [(40, 50), (320, 240), (1920, 1080), (7, 9)])
 def test_corner_intensity_and_general_detector(api, orc, w, h):
     """Shi-Tomasi / Harris gradient corner intensity (running box sums in the reference's order: bit-exact), then
@@ -761,8 +809,17 @@ def test_corner_intensity_and_general_detector(api, orc, w, h):
         got = [(p.x, p.y) for p in det.getMaximums()]
         exp = orc.nonmax(orc.Gray.from_array(orc.corner_intensity(dxo, dyo, 2, "shitomasi")), 2, 1.0, 2)
         assert len(got) > 5 and got == [(int(x), int(y)) for x, y in exp]
-        with pytest.raises(RuntimeError):
-            det.setMaxFeatures(10)
+        # maxFeatures > 0: SelectNBestFeatures on the maxima (GeneralFeatureDetector.java:143-160); same QuickSelect exchange sequence as the oracle
+        inten_o = orc.Gray.from_array(orc.corner_intensity(dxo, dyo, 2, "shitomasi"))
+        for nmax in (1, 10, len(exp) - 1, len(exp), len(exp) + 5):
+            det.setMaxFeatures(nmax)
+            det.process(G(api, img), dx, dy)
+            got = [(p.x, p.y) for p in det.getMaximums()]
+            want = orc.select_nbest(inten_o, exp, nmax, positive=True)
+            assert got == [(int(x), int(y)) for x, y in want], nmax
+        sel = api.SelectNBestFeatures(3)
+        sel.process(det.getIntensity(), [api.Point2D_I16(int(x), int(y)) for x, y in exp], False)   # negative: the least intense
+        assert [(p.x, p.y) for p in sel.getBestCorners()] == [(int(x), int(y)) for x, y in orc.select_nbest(inten_o, exp, 3, positive=False)]
     with pytest.raises(api.IllegalArgumentException):
         api.FactoryIntensityPointAlg.shiTomasi(5, False, api.GrayF32).process(api.GrayF32(6, 6), api.GrayF32(6, 6), api.GrayF32(1, 1))
 

@@ -712,3 +712,35 @@ def test_integer_variants_stage_level(orc):
         ok = 0 <= ax < 60 and 0 <= ay < 70 and 0 <= bx < 60 and 0 <= by < 70
         bit = (int(edge[k // 32]) >> (31 - k % 32)) & 1
         assert bit == (1 if ok and img[ay, ax] < img[by, bx] else 0)
+
+
+def test_select_nbest_literals(orc):  # FT:alg/feature/detect/extract/TestSelectNBestFeatures.java:36-68 (testExtra), :73-93 (testTooLittle)
+    a = np.zeros((20, 10), np.float32)
+    a[10, 5] = -3; a[10, 4] = -3.5; a[11, 5] = 0; a[8, 8] = 10
+    img = orc.Gray.from_array(a)
+    corners = np.array([[5, 10], [4, 10], [5, 11], [8, 8]], np.int16)
+    found = orc.select_nbest(img, corners, 3, positive=True)
+    assert len(found) == 3 and tuple(found[0]) == (8, 8)
+    assert {tuple(p) for p in found} == {(8, 8), (5, 11), (5, 10)}
+    found = orc.select_nbest(img, corners, 3, positive=False)
+    assert len(found) == 3 and tuple(found[0]) == (4, 10)
+    # N larger than the list: an unpruned copy in the original order
+    found = orc.select_nbest(img, corners, 20, positive=True)
+    assert found.tolist() == corners.tolist()
+
+
+def test_select_nbest_keeps_the_n_largest(orc):
+    """Property the unpinned QuickSelect order cannot change: the kept set is the N largest intensities (no ties here), and
+    FastHessianFeatureDetector with maxFeaturesPerScale = N returns a subset of the unlimited detection."""
+    rand = orc.JavaRandom(99)
+    img = rand.fillUniform(orc.Gray(64, 48), 0, 100)
+    a = img.array()
+    pts = np.array([[x, y] for y in range(0, 48, 3) for x in range(0, 64, 3)], np.int16)
+    for n in (1, 7, 50, len(pts) - 1):
+        kept = orc.select_nbest(img, pts, n)
+        vals = sorted((a[y, x] for x, y in pts), reverse=True)
+        assert sorted((a[y, x] for x, y in kept), reverse=True) == vals[:n]
+    ii = orc.integral(orc.JavaRandom(5).fillUniform(orc.Gray(160, 120), 0, 100))
+    full = {tuple(p) for p in orc.fh_detect(ii, orc.FhCfg()).tolist()}
+    lim = orc.fh_detect(ii, orc.FhCfg(maxFeaturesPerScale=10)).tolist()
+    assert 0 < len(lim) < len(full) and {tuple(p) for p in lim} <= full
