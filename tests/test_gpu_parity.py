@@ -166,6 +166,30 @@ def test_fast_hessian_max_features_per_scale(api, orc, w, h, seed, nbest):
             _compare_surf(api, orc, dd, ref, im, k)
 
 
+def test_fast_hessian_random_shapes_and_configs(api, orc):
+    """Seeded sweep over frame shapes (every residue of W, H modulo the octave steps moves the inner / border split of the Hessian forms and
+    the NMS block grid) and detector configurations, key points bit-exact and in order.  Noise frames put key points right up to the borders."""
+    rng = np.random.default_rng(20240607)
+    checked = 0
+    for k in range(24):
+        w, h = int(rng.integers(60, 520)), int(rng.integers(60, 420))
+        cfg = {}
+        if k % 3 == 1:
+            cfg = dict(extractRadius=int(rng.integers(1, 4)), detectThreshold=float(rng.choice([0.5, 1.0, 10.0])))
+        elif k % 3 == 2:
+            cfg = dict(initialSampleSize=int(rng.integers(1, 3)), numberScalesPerOctave=int(rng.integers(3, 6)), numberOfOctaves=int(rng.integers(1, 5)),
+                       initialSize=int(rng.choice([9, 15])), scaleStepSize=int(rng.choice([6, 8])))
+        if k % 4 == 3:
+            cfg["maxFeaturesPerScale"] = int(rng.choice([5, 50, 500]))
+        ii = orc.integral(orc.noise_image(w, h, 1000 + k))
+        exp = orc.fh_detect(ii, orc.FhCfg(**cfg), threads=8)
+        det = api.FastHessianFeatureDetector(api.ConfigFastHessian(**cfg))
+        det.detect(G(api, ii))
+        assert np.array_equal(det.getFoundPoints(), exp), (w, h, cfg)
+        checked += len(exp)
+    assert checked > 5000
+
+
 def test_fast_hessian_image_smaller_than_kernel(api, orc):
     ii = orc.integral(orc.noise_image(20, 20, 3))  # 27 > 20: no octave runs (FastHessianFeatureDetector.java:178)
     det = api.FastHessianFeatureDetector(); det.detect(G(api, ii))
