@@ -240,6 +240,32 @@ def test_surf_detect_describe_parity(api, orc, stable):
     assert isinstance(d, api.BrightFeature) and dd.getRadius(0) == dd._results()[0][0][2] * 2.0 and p.x == dd._results()[0][0][0]
 
 
+@pytest.mark.parametrize("stable", [True, False])
+def test_surf_random_shapes_batched(api, orc, stable):
+    """Seeded sweep of frame shapes through detect + describe, several frames per batch: key points bit-exact, descriptors within
+    tolerance.  Blob frames (S-blobs of SURVEY 8d, scaled down) put large-scale key points next to the borders, where the descriptor
+    and orientation samplers switch to their bounds-checked forms."""
+    rng = np.random.default_rng(77 if stable else 78)
+    ref = orc.Surf(stable)
+    for k in range(3):
+        w, h = int(rng.integers(150, 420)), int(rng.integers(120, 330))
+        dd = (api.FactoryDetectDescribe.surfStable if stable else api.FactoryDetectDescribe.surfFast)(None, None, None, api.GrayF32)
+        frames = []
+        for j in range(3):
+            yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+            a = np.full((h, w), 50.0)
+            for _ in range(max(4, w * h // 2500)):
+                cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+                sg = float(rng.choice([2, 3, 5, 8, 13]))
+                amp = float(rng.uniform(40, 100) * rng.choice([-1, 1]))
+                a += amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
+            a += rng.uniform(0, 2, (h, w))
+            frames.append(orc.Gray.from_array(a.astype(np.float32)))
+        dd.detectBatch([G(api, f) for f in frames])
+        total = sum(_compare_surf(api, orc, dd, ref, f, j) for j, f in enumerate(frames))
+        assert total > 30, (w, h)
+
+
 def test_surf_batch_equals_single(api, orc):
     dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32)
     ref = orc.Surf(True)
