@@ -29,6 +29,42 @@ struct ConvParams {
 	float k[BHIP_MAX_TAPS];
 };
 
+// Interior taps.  The loads of one output are independent: issue them together (a run-time tap loop waits for each load before the next).
+// Unrolled widths (ConvolveImageUnrolled_SB_F32_F32 / ConvolveDownNoBorderUnrolled_F32_F32): total = s[0]*k[0]; total += s[i]*k[i] ...
+template <int KW>
+__device__ __forceinline__ float tapsFirstAssigns(const float* __restrict__ s, long long step, const float* k) {
+	float v[KW];
+#pragma unroll
+	for (int i = 0; i < KW; i++) v[i] = s[i * step];
+	float total = v[0] * k[0];
+#pragma unroll
+	for (int i = 1; i < KW; i++) total += v[i] * k[i];
+	return total;
+}
+__device__ __forceinline__ float tapsUnrolled(const float* __restrict__ s, long long step, const float* k, int kw) {
+	switch (kw) {
+	case 3: return tapsFirstAssigns<3>(s, step, k);
+	case 5: return tapsFirstAssigns<5>(s, step, k);
+	case 7: return tapsFirstAssigns<7>(s, step, k);
+	case 9: return tapsFirstAssigns<9>(s, step, k);
+	default: return tapsFirstAssigns<11>(s, step, k);
+	}
+}
+// Standard form (ConvolveImageStandard_SB / ConvolveDownNoBorderStandard): total = 0; total += s[i]*k[i] in order, loads four at a time
+__device__ __forceinline__ float tapsStandard(const float* __restrict__ s, long long step, const float* k, int kw) {
+	float total = 0;
+	int i = 0;
+	for (; i + 4 <= kw; i += 4) {
+		const float v0 = s[i * step], v1 = s[(i + 1) * step], v2 = s[(i + 2) * step], v3 = s[(i + 3) * step];
+		total += v0 * k[i];
+		total += v1 * k[i + 1];
+		total += v2 * k[i + 2];
+		total += v3 * k[i + 3];
+	}
+	for (; i < kw; i++) total += s[i * step] * k[i];
+	return total;
+}
+
 template <bool VERTICAL>
 __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,15 +80,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 	if (interior && P.mode == 3) return;
 	if (interior && P.mode != 2) {
 		const float* s = src - offL * step;
-		float total;
-		if (P.unrolled) {
-			total = s[0] * P.k[0];
-			for (int k = 1; k < P.kw; k++) total += s[k * step] * P.k[k];
-		} else {
-			total = 0;
-			for (int k = 0; k < P.kw; k++) total += s[k * step] * P.k[k];
-		}
-		result = total;
+		result = P.unrolled ? tapsUnrolled(s, step, P.k, P.kw) : tapsStandard(s, step, P.k, P.kw);
 	} else {
 		if (P.mode == 0) return;
 		const int k0 = max(0, offL - pos);
@@ -96,6 +124,7 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 		}
 	}
 	dim3 grid((width + 255) / 256, height);
+	ProfScope prof(ctx, vertical ? "k_conv_v" : "k_conv_h", 8.0 * width * height);
 	if (vertical) hipLaunchKernelGGL(k_conv<true>, grid, dim3(256), 0, ctx->stream, P);
 	else hipLaunchKernelGGL(k_conv<false>, grid, dim3(256), 0, ctx->stream, P);
 	BHIP_HIP(ctx, hipGetLastError());
@@ -166,15 +195,7 @@ __global__ __launch_bounds__(256) void k_conv_down(ConvDownParams P) {
 		result = total / weight;
 	} else {
 		const float* s0 = src - r * step;
-		float total;
-		if (P.unrolled) {
-			total = s0[0] * P.k[0];
-			for (int k = 1; k < P.kw; k++) total += s0[k * step] * P.k[k];
-		} else {
-			total = 0;
-			for (int k = 0; k < P.kw; k++) total += s0[k * step] * P.k[k];
-		}
-		result = total;
+		result = P.unrolled ? tapsUnrolled(s0, step, P.k, P.kw) : tapsStandard(s0, step, P.k, P.kw);
 	}
 	P.out[(long long)blockIdx.z * P.outImageStride + (long long)oy * P.outStride + ox] = result;
 }
