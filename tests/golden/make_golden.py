@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/config1_small.npz: a frozen run of BASELINE config 1 (two S-noise frames through surfStable, greedy mutual-best
+Euclidean-squared association), scaled down to 320x240 so the file stays small.
+
+IMPORTANT: the vectors come from oracle/ -- the C++ restatement of the reference's Java code -- NOT from BoofCV itself.  This image has no
+JVM and the reference ships no stored outputs, so these fixtures cannot pin parity with the Java build; they pin the
+restatement (a change in the oracle's arithmetic shows up here) and give the GPU tests a target that does not depend on the oracle being
+rebuilt.  Parity with Java rests on the reference's own known-answer literals (tests/test_oracle_known_answers.py) plus construction.
+
+Inputs are regenerated from the seeds (ImageMiscOps.fillUniform with java.util.Random, restated in oracle/), so only outputs are stored:
+key points (x, y, scale: float64, exact), orientation, Laplacian sign, descriptors as float32 (the parity bar is 1e-5), association
+pairs and fit scores, and BRIEF-512 words at the first 64 key points.
+
+    python tests/golden/make_golden.py          # rewrites the fixture (review the diff!)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+W, H, SEEDS = 320, 240, (234, 235)
+
+
+def generate():
+    from oracle import pyoracle as orc
+    orc.build()
+    out = {}
+    descs = []
+    for k, seed in enumerate(SEEDS):
+        img = orc.noise_image(W, H, seed)
+        s = orc.Surf(True)
+        n = s.detect(img)
+        xys, ang, white, desc = s.fetch()
+        out["xys%d" % k] = xys
+        out["angle%d" % k] = ang
+        out["white%d" % k] = white.astype(np.uint8)
+        out["desc%d" % k] = desc.astype(np.float32)
+        descs.append(desc)
+        if k == 0:
+            sp, cp = orc.brief_definition()
+            out["brief0"] = orc.brief_describe(img, xys[:64, :2], 16, sp, cp)
+    pairs, fit = orc.associate_l2(descs[0], descs[1], backwards=True)
+    out["pairs"] = pairs
+    out["fit"] = fit
+    return out
+
+
+if __name__ == "__main__":
+    data = generate()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config1_small.npz")
+    np.savez_compressed(path, **data)
+    print(path, {k: v.shape for k, v in data.items()}, os.path.getsize(path), "bytes")

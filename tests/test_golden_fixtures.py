@@ -1,0 +1,67 @@
+"""tests/golden/config1_small.npz: frozen oracle outputs for a scaled-down BASELINE config 1 (see tests/golden/make_golden.py for what
+the fixture can and cannot pin: it is produced by the C++ restatement, not by the Java reference).
+  CPU: today's oracle reproduces the fixture (guards the checker against silent changes).
+  GPU: the HIP path matches the fixture through the C ABI without running the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+FIX = os.path.join(HERE, "golden", "config1_small.npz")
+DESC_TOL = 1e-5   # SURVEY hard part 4: descriptor parity bar; the fixture stores float32 (6e-8 relative)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return dict(np.load(FIX, allow_pickle=False))
+
+
+def test_oracle_reproduces_golden_fixture(orc, golden):
+    import make_golden
+    now = make_golden.generate()
+    assert set(now) == set(golden)
+    for k in ("xys0", "xys1", "white0", "white1", "pairs", "brief0"):
+        assert np.array_equal(now[k], golden[k]), k
+    for k in ("angle0", "angle1", "fit"):
+        assert np.allclose(now[k], golden[k], rtol=0, atol=1e-12), k
+    for k in ("desc0", "desc1"):
+        assert np.array_equal(now[k], golden[k]), k     # both went through the same float32 rounding
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_fixture(golden):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    import make_golden
+    from boofcv_amd import api
+    from oracle import pyoracle as orc   # inputs only: the seeded java.util.Random frames (fillUniform); no oracle result is used below
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32)
+    frames = [orc.noise_image(make_golden.W, make_golden.H, s) for s in make_golden.SEEDS]
+    dd.detectBatch([api.GrayF32.wrap(f.array()) for f in frames])
+    descs = []
+    for k in range(2):
+        dd.selectImage(k)
+        xys, ang, white, desc = dd._results()
+        assert np.array_equal(xys, golden["xys%d" % k])                      # bit-exact, reference order
+        assert np.array_equal(white, golden["white%d" % k].astype(white.dtype))
+        derr = np.max(np.abs(desc - golden["desc%d" % k].astype(np.float64)), axis=1)
+        assert (derr <= DESC_TOL).mean() >= 0.999
+        dang = np.abs(np.angle(np.exp(1j * (ang - golden["angle%d" % k]))))
+        assert np.median(dang) < 1e-12
+        descs.append(desc)
+    # association on the FIXTURE's descriptors widened back to double is not the same input as the oracle's; associate the GPU's own
+    # descriptors and require agreement wherever the winning margin is above the descriptor tolerance
+    a = api.FactoryAssociation.greedy(api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True)
+    a.setSource(descs[0]); a.setDestination(descs[1]); a.associate()
+    pairs = a.getPairs()
+    agree = (pairs == golden["pairs"]).mean()
+    assert agree >= 0.995, agree
+    same = pairs == golden["pairs"]
+    assert np.allclose(a.getFitQuality()[same & (pairs >= 0)], golden["fit"][same & (pairs >= 0)], atol=1e-4)
+    sp, cp = orc.brief_definition()
+    b = api.DescribePointBrief(16, sp, cp); b.setImage(api.GrayF32.wrap(frames[0].array()))
+    assert np.array_equal(b.processAll(golden["xys0"][:64, :2]), golden["brief0"])
