@@ -11,6 +11,7 @@
 // while every lane owns one row's chain; pass 2 is naturally coalesced (a wave owns 64 adjacent columns).
 // Bound: HBM.  Algorithmic bytes: 4P read + 4P write per pass.
 #include "common.h"
+#include <cstdlib>
 
 #define TILE 64
 #define TPAD 65   // (row*65 + k) % 32 == (row + k) % 32: conflict-free column walks for ds_read/write_b32
@@ -119,8 +120,182 @@ __global__ __launch_bounds__(256) void k_integral_cols(ImgViewW io) {
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Single-pass form for large batches: one workgroup (16 waves) per image, the input read once and the integral image written once
+// (8P bytes instead of 16P).  Both chains stay sequential:
+//   * a wave owns a band of 64 rows and walks it left to right in 64x32 tiles; lane = row keeps that row's running sum in a register
+//     across the tiles (the row chain), exactly as k_integral_rows does;
+//   * inside a tile lane = column then adds the band's row sums on top of the integral-image row just above the band (the column
+//     chain).  That row travels through LDS: the wave owning the band above left it in a two-slot ring one step earlier; across the
+//     wrap from wave 15 to wave 0 (images with more than 16 bands) it waits in a full-width row buffer.
+// Band b starts one step after band b - 1 (a diagonal pipeline over the 16 waves); with more than 16 bands a wave takes band b + 16
+// when it has finished band b.  Every wave runs the same number of steps and meets one barrier per step, whether it has a tile or not.
+// Step of (band b, tile j): (b / 16) * max(nTiles, 16) + b % 16 + j.  The barrier orders LDS only (s_waitcnt lgkmcnt(0) + s_barrier):
+// nothing read by another wave goes through global memory, so stores and the next tile's loads stay in flight across steps.
+// ---------------------------------------------------------------------------------------------------------------
+#define FT 32   // tile columns
+#define FP 33   // LDS pitch: (row * 33 + k) % 32 == (row + k) % 32
+#define FUSED_TILE_FLOATS (16 * 64 * FP)
+#define FUSED_RING_FLOATS (2 * 16 * FT)
+#define FUSED_MIN_BATCH 128   // an image takes ~0.8 ms through its one workgroup whatever the batch (120 pipeline steps of ~7 us, set by
+                              // memory latency with one tile of look-ahead); the two streaming passes are faster below ~128 images
+                              // (1080p: 0.72 vs 0.84 ms at 96, 0.96 vs 0.85 at 128, 1.81 vs 1.08-1.16 at 256)
+
+__global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW out) {
+	extern __shared__ float fusedLds[];   // [16][64 * FP] tiles | [2][16][FT] ring | [W] wrap row (only with more than 16 bands)
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	float* tile = fusedLds + wave * 64 * FP;
+	float* ring = fusedLds + FUSED_TILE_FLOATS;
+	float* wrapRow = ring + FUSED_RING_FLOATS;
+	const int half = lane >> 5, c = lane & 31;
+	const int W = in.width, H = in.height;
+	const float* __restrict__ src = in.data + (long long)blockIdx.x * in.imageStride;
+	float* __restrict__ dst = out.data + (long long)blockIdx.x * out.imageStride;
+	const int nTiles = (W + FT - 1) / FT;
+	const int nBands = (H + 63) / 64;
+	const int rounds = (nBands + 15) / 16;
+	const int S = max(nTiles, 16);
+	const int T = (rounds - 1) * S + 16 + nTiles;   // steps; identical for every wave
+
+	// (band, tile) of this wave at step t, or band = -1
+	auto slot = [&](int t, int& b, int& j) {
+		const int u = t - wave;
+		b = -1; j = 0;
+		if (u < 0) return;
+		const int r = u / S;
+		j = u - r * S;
+		const int bb = wave + 16 * r;
+		if (r < rounds && bb < nBands && j < nTiles) b = bb;
+	};
+	// Full tiles (64 rows, 32 columns inside the image: all but the last band / last tile) take a path without per-element guards and
+	// with scalar row bases + one 32-bit lane offset, so a load or store costs one instruction; the guarded form handles the edges.
+	const unsigned laneOffIn = (unsigned)(half * in.stride + c), laneOffOut = (unsigned)(half * out.stride + c);
+	auto loadTile = [&](int b, int j, float* v) {
+		const int y0 = 64 * b;
+		const int nrows = min(64, H - y0);
+		if (nrows == 64 && FT * j + FT <= W) {
+			const float* __restrict__ base = src + (long long)y0 * in.stride + FT * j;   // wave-uniform
+#pragma unroll
+			for (int i = 0; i < 32; i++) v[i] = (base + (long long)(2 * i) * in.stride)[laneOffIn];
+			return;
+		}
+		const int col = FT * j + c;
+#pragma unroll
+		for (int i = 0; i < 32; i++) {
+			const int row = 2 * i + half;
+			v[i] = (row < nrows && col < W) ? src[(long long)(y0 + row) * in.stride + col] : 0.0f;
+		}
+	};
+	float v[32];
+	float carry = 0.0f;
+	{
+		int b, j;
+		slot(0, b, j);
+		if (b >= 0) loadTile(b, j, v);
+	}
+	for (int t = 0; t < T; t++) {
+		int b, j;
+		slot(t, b, j);
+		if (b >= 0) {
+			const int y0 = 64 * b;
+			const int nrows = min(64, H - y0);
+			if (j == 0) carry = 0.0f;
+			const int colC = FT * j + c;
+			// the integral-image row above this band, for the tile's columns
+			float top = 0.0f;
+			if (b > 0 && half == 0) top = wave > 0 ? ring[((t - 1) & 1) * 16 * FT + (wave - 1) * FT + c] : wrapRow[min(colC, W - 1)];
+#pragma unroll
+			for (int i = 0; i < 32; i++) tile[(2 * i + half) * FP + c] = v[i];
+			// next step's tile: its loads complete under this step's scans
+			{
+				int nb, nj;
+				slot(t + 1, nb, nj);
+				if (nb >= 0) loadTile(nb, nj, v);
+			}
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			// row chain: lane = row
+			if (lane < nrows) {
+				float* mine = tile + lane * FP;
+#pragma unroll
+				for (int k0 = 0; k0 < FT; k0 += 16) {
+					float q[16];
+#pragma unroll
+					for (int k = 0; k < 16; k++) q[k] = mine[k0 + k];
+#pragma unroll
+					for (int k = 0; k < 16; k++) { carry += q[k]; q[k] = carry; }   // columns past W hold 0: harmless, never stored
+#pragma unroll
+					for (int k = 0; k < 16; k++) mine[k0 + k] = q[k];
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			// column chain: lane = column (first half wave); ii[y] = ii[y-1] + s[y], and ii[0] = s[0] on the image's first row
+			if (half == 0) {
+				float acc = top;
+				int r0 = 0;
+				if (b == 0) { acc = tile[c]; r0 = 1; }
+				// 16 rows at a time: the LDS reads of a batch are issued together, then the dependent adds, then the writes
+#pragma unroll
+				for (int rb = 0; rb < 64; rb += 16) {
+					if (rb < nrows) {
+						float q[16];
+#pragma unroll
+						for (int k = 0; k < 16; k++) q[k] = tile[(rb + k) * FP + c];   // rows past nrows: guarded below
+#pragma unroll
+						for (int k = 0; k < 16; k++)
+							if (rb + k >= r0 && rb + k < nrows) { acc = acc + q[k]; q[k] = acc; }
+#pragma unroll
+						for (int k = 0; k < 16; k++)
+							if (rb + k >= r0 && rb + k < nrows) tile[(rb + k) * FP + c] = q[k];
+					}
+				}
+				// the band's last row for the band below: next wave's ring slot, or the wrap row when that band belongs to wave 0
+				if (b + 1 < nBands) {
+					if (wave < 15) ring[(t & 1) * 16 * FT + wave * FT + c] = acc;
+					else if (colC < W) wrapRow[colC] = acc;
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			if (nrows == 64 && FT * j + FT <= W) {
+				float* __restrict__ base = dst + (long long)y0 * out.stride + FT * j;   // wave-uniform
+#pragma unroll
+				for (int i = 0; i < 32; i++) (base + (long long)(2 * i) * out.stride)[laneOffOut] = tile[(2 * i + half) * FP + c];
+			} else {
+#pragma unroll
+				for (int i = 0; i < 32; i++) {
+					const int row = 2 * i + half;
+					if (row < nrows && colC < W) dst[(long long)(y0 + row) * out.stride + colC] = tile[row * FP + c];
+				}
+			}
+		} else {
+			int nb, nj;
+			slot(t + 1, nb, nj);
+			if (nb >= 0) loadTile(nb, nj, v);
+		}
+		// LDS-only barrier: ring / wrap-row writes of this step are complete and visible; global loads and stores are not waited for
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+	}
+}
+
 int bhip_launch_integral(bhip_ctx* ctx, ImgView in, ImgViewW out, int batch) {
 	if (in.width <= 0 || in.height <= 0 || batch <= 0) return BHIP_OK;
+	static int twoPass = -1;
+	if (twoPass < 0) { const char* e = getenv("BHIP_INTEGRAL_TWO_PASS"); twoPass = (e && e[0] == '1') ? 1 : 0; }   // parity cross-check / A-B timing
+	// one workgroup per image only fills the chip with a large batch; small batches keep the two streaming passes
+	const size_t lds = ((size_t)FUSED_TILE_FLOATS + FUSED_RING_FLOATS + (in.height > 1024 ? in.width : 0)) * sizeof(float);
+	if (!twoPass && batch >= FUSED_MIN_BATCH && in.data != out.data && lds <= 160 * 1024) {
+		static size_t attrLds = 0;
+		if (lds > attrLds) {
+			BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_integral_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			attrLds = lds;
+		}
+		ProfScope ps(ctx, "k_integral_fused", 8.0 * in.width * in.height * batch);   // 4P read + 4P write
+		hipLaunchKernelGGL(k_integral_fused, dim3(batch), dim3(1024), lds, ctx->stream, in, out);
+		BHIP_HIP(ctx, hipGetLastError());
+		return BHIP_OK;
+	}
 	const long long totalRows = (long long)in.height * batch;
 	const long long groups = (totalRows + TILE - 1) / TILE;
 	const unsigned blocks = (unsigned)((groups + 3) / 4);

@@ -321,6 +321,21 @@ def test_integral_from_detect_is_bit_exact(api, orc):
     assert np.array_equal(bits(dd.fetchIntegral(0, 333, 111)), bits(orc.integral(img).array()))
 
 
+@pytest.mark.parametrize("w,h,batch", [(100, 130, 128), (33, 65, 130), (700, 1100, 128), (513, 64, 129), (1920, 1080, 128), (1921, 1081, 128), (64, 2100, 128)])
+def test_integral_single_pass_batched(api, orc, w, h, batch):
+    """Batches of 128+ frames take the single-pass integral kernel (one workgroup per image, row and column chains both sequential): every
+    frame's integral image is bit-exact.  Shapes cover fewer than / more than 16 column tiles, more than 16 row bands (a wave takes a second
+    band), ragged last tiles and bands.  Large values (up to 1e4 per pixel) make every addition round."""
+    dd = api.FactoryDetectDescribe.surfFast(api.ConfigFastHessian(detectThreshold=1e12), None, None, api.GrayF32)   # no key points: integral only
+    rng = np.random.default_rng(w * 7 + h)
+    frames = [(rng.uniform(0, 1e4, (h, w))).astype(np.float32) for _ in range(3)]
+    idx = [int(k) for k in rng.integers(0, 3, batch)]
+    dd.detectBatch([api.GrayF32.wrap(frames[k]) for k in idx])
+    want = [orc.integral(orc.Gray.from_array(f)).array() for f in frames]
+    for pos in sorted({0, 1, batch // 2, batch - 1}):
+        assert np.array_equal(bits(dd.fetchIntegral(pos, w, h)), bits(want[idx[pos]])), pos
+
+
 # ------------------------------------------------------------------------------------------------------------------ association
 def _col(*v):
     return np.array(v, np.float64).reshape(-1, 1)
