@@ -173,10 +173,21 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 	auto loadTile = [&](int b, int j, float* v) {
 		const int y0 = 64 * b;
 		const int nrows = min(64, H - y0);
-		if (nrows == 64 && FT * j + FT <= W) {
+		if (FT * j + FT <= W) {
 			const float* __restrict__ base = src + (long long)y0 * in.stride + FT * j;   // wave-uniform
+			if (nrows == 64) {
 #pragma unroll
-			for (int i = 0; i < 32; i++) v[i] = (base + (long long)(2 * i) * in.stride)[laneOffIn];
+				for (int i = 0; i < 32; i++) v[i] = (base + (long long)(2 * i) * in.stride)[laneOffIn];
+			} else {
+				// last band: the row tests are wave-uniform (scalar branches), only an odd last row needs a lane predicate
+#pragma unroll
+				for (int i = 0; i < 32; i++) {
+					const float* rp = base + (long long)(2 * i) * in.stride;
+					if (2 * i + 1 < nrows) v[i] = rp[laneOffIn];
+					else if (2 * i < nrows) v[i] = half == 0 ? rp[laneOffIn] : 0.0f;
+					else v[i] = 0.0f;
+				}
+			}
 			return;
 		}
 		const int col = FT * j + c;
@@ -258,10 +269,19 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 			}
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			if (nrows == 64 && FT * j + FT <= W) {
+			if (FT * j + FT <= W) {
 				float* __restrict__ base = dst + (long long)y0 * out.stride + FT * j;   // wave-uniform
+				if (nrows == 64) {
 #pragma unroll
-				for (int i = 0; i < 32; i++) (base + (long long)(2 * i) * out.stride)[laneOffOut] = tile[(2 * i + half) * FP + c];
+					for (int i = 0; i < 32; i++) (base + (long long)(2 * i) * out.stride)[laneOffOut] = tile[(2 * i + half) * FP + c];
+				} else {
+#pragma unroll
+					for (int i = 0; i < 32; i++) {
+						float* rp = base + (long long)(2 * i) * out.stride;
+						if (2 * i + 1 < nrows) rp[laneOffOut] = tile[(2 * i + half) * FP + c];
+						else if (2 * i < nrows && half == 0) rp[laneOffOut] = tile[(2 * i) * FP + c];
+					}
+				}
 			} else {
 #pragma unroll
 				for (int i = 0; i < 32; i++) {
