@@ -463,7 +463,22 @@ __global__ __launch_bounds__(64) void k_corner_rows(CornerParams P) {
 		tXX += dx * dx; tXY += dx * dy; tYY += dy * dy;
 	}
 	oXX[r] = tXX; oXY[r] = tXY; oYY[r] = tYY;
-	for (int i = ww; i < W; i++) {
+	int i = ww;
+	// eight steps at a time: the 32 loads of a batch are independent and issued together, the chain arithmetic keeps its order
+	for (; i + 8 <= W; i += 8) {
+		float ax[8], ay[8], bx[8], by[8], rXX[8], rXY[8], rYY[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) { ax[k] = X[i - ww + k]; ay[k] = Y[i - ww + k]; bx[k] = X[i + k]; by[k] = Y[i + k]; }
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			tXX -= ax[k] * ax[k]; tXY -= ax[k] * ay[k]; tYY -= ay[k] * ay[k];
+			tXX += bx[k] * bx[k]; tXY += bx[k] * by[k]; tYY += by[k] * by[k];
+			rXX[k] = tXX; rXY[k] = tXY; rYY[k] = tYY;
+		}
+#pragma unroll
+		for (int k = 0; k < 8; k++) { oXX[i - r + k] = rXX[k]; oXY[i - r + k] = rXY[k]; oYY[i - r + k] = rYY[k]; }
+	}
+	for (; i < W; i++) {
 		float dx = X[i - ww], dy = Y[i - ww];
 		tXX -= dx * dx; tXY -= dx * dy; tYY -= dy * dy;
 		dx = X[i]; dy = Y[i];
@@ -494,7 +509,24 @@ __global__ __launch_bounds__(256) void k_corner_cols(CornerParams P) {
 		tXX += hXX[s]; tXY += hXY[s]; tYY += hYY[s];
 	}
 	P.intensity[(long long)r * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
-	for (int y = r + 1; y < H - r; y++) {
+	int y = r + 1;
+	for (; y + 8 <= H - r; y += 8) {
+		float a[3][8], b[3][8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			const long long in = (long long)(y + k + r) * W + x, out = in - (long long)kw * W;
+			a[0][k] = hXX[out]; a[1][k] = hXY[out]; a[2][k] = hYY[out];
+			b[0][k] = hXX[in]; b[1][k] = hXY[in]; b[2][k] = hYY[in];
+		}
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			tXX = tXX - a[0][k]; tXX += b[0][k];
+			tXY = tXY - a[1][k]; tXY += b[1][k];
+			tYY = tYY - a[2][k]; tYY += b[2][k];
+			P.intensity[(long long)(y + k) * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
+		}
+	}
+	for (; y < H - r; y++) {
 		const long long in = (long long)(y + r) * W + x, out = in - (long long)kw * W;
 		tXX = tXX - hXX[out]; tXX += hXX[in];
 		tXY = tXY - hXY[out]; tXY += hXY[in];
@@ -577,7 +609,17 @@ __global__ __launch_bounds__(64) void k_mean_rows(const float* __restrict__ in, 
 	float total = 0;
 	for (int i = 0; i < kw; i++) total += r[i];
 	o[radius] = total / divisor;
-	for (int i = kw; i < width; i++) {
+	int i = kw;
+	for (; i + 16 <= width; i += 16) {
+		float a[16], b[16], q[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) { a[k] = r[i - kw + k]; b[k] = r[i + k]; }
+#pragma unroll
+		for (int k = 0; k < 16; k++) { total -= a[k]; total += b[k]; q[k] = total / divisor; }
+#pragma unroll
+		for (int k = 0; k < 16; k++) o[i - radius + k] = q[k];
+	}
+	for (; i < width; i++) {
 		total -= r[i - kw];
 		total += r[i];
 		o[i - radius] = total / divisor;
@@ -591,7 +633,19 @@ __global__ __launch_bounds__(256) void k_mean_cols(const float* __restrict__ in,
 	float total = 0;
 	for (int k = 0; k < kw; k++) total += in[(long long)k * inStride + x];
 	out[(long long)radius * outStride + x] = total / divisor;
-	for (int y = radius + 1; y < height - radius; y++) {
+	int y = radius + 1;
+	for (; y + 8 <= height - radius; y += 8) {
+		float a[8], b[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) { a[k] = in[(long long)(y + k + radius - kw) * inStride + x]; b[k] = in[(long long)(y + k + radius) * inStride + x]; }
+#pragma unroll
+		for (int k = 0; k < 8; k++) {
+			total = total - a[k];
+			total += b[k];
+			out[(long long)(y + k) * outStride + x] = total / divisor;
+		}
+	}
+	for (; y < height - radius; y++) {
 		total = total - in[(long long)(y + radius - kw) * inStride + x];
 		total += in[(long long)(y + radius) * inStride + x];
 		out[(long long)y * outStride + x] = total / divisor;
