@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 def build(force=False):
     """Compile liboracle.so with g++ (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_capi.cpp", "boof_oracle.hpp", "boof_oracle_ip.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_capi.cpp", "boof_oracle.hpp", "boof_oracle_ip.hpp", "boof_oracle_int.hpp")]
     if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
