@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libboofhip.so")
+# BHIP_LIB selects another build of the same ABI (scripts/ use libboofhip_exp.so, the -DBHIP_EXPERIMENTS build, for ablation runs)
+LIB_PATH = os.environ.get("BHIP_LIB") or os.path.join(_HERE, "libboofhip.so")
 
 BHIP_OK = 0
 BHIP_ERR_INVALID = -1
@@ -99,6 +100,17 @@ SIGNATURES = {
     "bhip_fh_detect_s32": (_i, [_vp, P(FhCfg), _i32p, _i, _i, _i, _i, _dp, _i, _ip]),
     "bhip_brief_u8": (_i, [_vp, _u8p, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _dp, _i, _i32p]),
     "bhip_brief_f32": (_i, [_vp, _fp, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _dp, _i, _i32p]),
+    "bhip_conv_h_dev_f32": (_i, [_vp, _fp, _i, _i, _vp, _ll, _i, _i, _i, _i, _vp, _ll, _i]),
+    "bhip_conv_v_dev_f32": (_i, [_vp, _fp, _i, _i, _vp, _ll, _i, _i, _i, _i, _vp, _ll, _i]),
+    "bhip_conv_norm_h_dev_f32": (_i, [_vp, _fp, _i, _i, _vp, _ll, _i, _i, _i, _i, _vp, _ll, _i]),
+    "bhip_conv_norm_v_dev_f32": (_i, [_vp, _fp, _i, _i, _vp, _ll, _i, _i, _i, _i, _vp, _ll, _i]),
+    "bhip_gaussian_dev_f32": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _d, _i, _vp, _ll, _i]),
+    "bhip_sobel_dev_f32": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _vp, _vp, _ll, _i, _i]),
+    "bhip_three_dev_f32": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _vp, _vp, _ll, _i, _i]),
+    "bhip_gradient_intensity_dev_f32": (_i, [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _i, _vp, _ll, _i]),
+    "bhip_nonmax_block_dev_f32": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
+    "bhip_corner_intensity_dev_f32": (_i, [_vp, _i, _i, _f, _vp, _vp, _ll, _i, _i, _i, _i, _vp, _ll, _i]),
+    "bhip_brief_dev_f32": (_i, [_vp, _vp, _ll, _i, _i, _i, _i, _i, _i, _i32p, _i32p, _vp, _ip, _vp]),
 }
 
 _lib = None

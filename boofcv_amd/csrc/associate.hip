@@ -265,8 +265,7 @@ static int phase1(bhip_ctx* ctx, bool hamming, const E* src, int nsLocal, int sr
 	}
 	// BRIEF-512 (16 words) runs on the int8 matrix cores (assoc_ham_mfma.hip: exact integer scores, same partial records);
 	// BHIP_HAM_VALU=1 keeps the popcount scan below (cross-check)
-	static int hamValu = -1;
-	if (hamValu < 0) { const char* e = getenv("BHIP_HAM_VALU"); hamValu = (e && e[0] == '1') ? 1 : 0; }
+	const bool hamValu = bhip_env_flag("BHIP_HAM_VALU");   // parity cross-check: popcount scan instead of the int8 matrix cores
 	const bool hamMfma = hamming && len == 16 && !hamValu;
 	const int rsplits = hamMfma ? bhip_ham_mfma_splits(nsLocal, nd) : chooseSplits(nsLocal, nd);
 	const int csplits = !colTop ? 0 : hamMfma ? bhip_ham_mfma_splits(nd, nsLocal) : chooseSplits(nd, nsLocal);

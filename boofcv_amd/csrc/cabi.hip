@@ -16,19 +16,6 @@ int bhip_assoc_phase1_ham(bhip_ctx* ctx, const int32_t* src, int nsLocal, int sr
 						  double* fit, void* colTop, DevBuf& work);
 int bhip_assoc_phase2(bhip_ctx* ctx, const void* colAll, int nranks, int nd, int nsLocal, int srcBegin, int* pairs, double* fit);
 int bhip_assoc_coltop_size();
-int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
-					 int height, float* out, int outStride);
-int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
-						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch);
-int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out);
-int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dx, const float* dy, int dStride, int width, int height,
-								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride);
-int bhip_launch_conv2d(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStride, int width, int height, float* out, int outStride);
-int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, int width, int height, int radius);
-int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out, int outStride, int width, int height, int radius);
-int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border);
-int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
-					  const int* compare, const double* xy, int n, int* out, bool u8 = false);
 int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, long long inImageStride, int inStride, int* out, long long outImageStride, int outStride,
 							int width, int height, int batch);
 
@@ -45,7 +32,7 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 
 // per-context scratch that the stateless entry points reuse
 struct CtxScratch {
-	DevBuf a, b, c, d, e, work;
+	DevBuf a, b, c, d, e, work, nmsBitmap, nmsPrefix, nmsPos, ipTmp, ipKernel;
 	AssocMfmaWork mfma;
 	int assocExactOnly = -1;  // BHIP_ASSOC_EXACT=1 forces the exact VALU association kernels (parity cross-check)
 };
@@ -110,7 +97,9 @@ int bhip_ctx_destroy(bhip_ctx* c) {
 	(void)hipStreamSynchronize(ctx->stream);
 	CtxScratch& s = ctx->scratch;
 	s.a.release(); s.b.release(); s.c.release(); s.d.release(); s.e.release(); s.work.release();
+	s.nmsBitmap.release(); s.nmsPrefix.release(); s.nmsPos.release(); s.ipTmp.release(); s.ipKernel.release();
 	bhip_assoc_mfma_release(s.mfma);
+	bhip_profile_release(ctx);
 	if (ctx->hostScratch) (void)hipHostFree(ctx->hostScratch);
 	if (ctx->ownStream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -162,11 +151,7 @@ struct FhDetector {
 	std::vector<int> counts;   // per image, host
 	long long total = 0;
 
-	static bool unfusedOnly() {
-		static int v = -1;
-		if (v < 0) { const char* e = getenv("BHIP_DETECT_UNFUSED"); v = (e && e[0] == '1') ? 1 : 0; }  // parity cross-check of the two detector paths
-		return v == 1;
-	}
+	static bool unfusedOnly() { return bhip_env_flag("BHIP_DETECT_UNFUSED"); }   // parity cross-check of the two detector paths
 	int makePlan(bhip_ctx* ctx, int width, int height) {
 		plan.clear();
 		if (cfg.numberScalesPerOctave > BHIP_MAX_LEVELS || cfg.numberScalesPerOctave < 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "numberScalesPerOctave out of range");
@@ -208,11 +193,7 @@ struct FhDetector {
 		return BHIP_OK;
 	}
 
-	static bool noShare() {
-		static int v = -1;
-		if (v < 0) { const char* e = getenv("BHIP_DETECT_NOSHARE"); v = (e && e[0] == '1') ? 1 : 0; }  // parity cross-check of the shared-level plan
-		return v == 1;
-	}
+	static bool noShare() { return bhip_env_flag("BHIP_DETECT_NOSHARE"); }   // parity cross-check of the shared-level plan
 	// Which octaves run fused, and which levels are copied from the octave below instead of being recomputed.  A box-filter response
 	// depends on (pixel, kernel size) only, and the default schedule repeats sizes: 15,27 | 27,51 | 51,99 are levels 1,3 of one octave and
 	// levels 0,1 of the next, on a lattice twice as coarse.  Sharing is enabled where the unrolled inner form and the clamped border
@@ -505,8 +486,11 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, boo
 	// processing order of the describe stage: key points of one image grouped by coarse tile (L2 locality of the gathers)
 	const int* perm = nullptr;
 	{
-		static int noOrder = -1;
-		if (noOrder < 0) { const char* e = getenv("BHIP_DESCRIBE_NOORDER"); noOrder = (e && e[0] == '1') ? 1 : 0; }
+#ifdef BHIP_EXPERIMENTS
+		const bool noOrder = bhip_env_flag("BHIP_DESCRIBE_NOORDER");
+#else
+		const bool noOrder = false;
+#endif
 		int maxCount = 0;
 		for (int c : s->det.counts) maxCount = std::max(maxCount, c);
 		if (!noOrder && total > 0) {
@@ -710,13 +694,17 @@ int bhip_surf_describe_points(bhip_surf* s, int image, const double* xy_scale, i
 // ---------------------------------------------------------------------------------------------------------------
 // stage-level entry points (host buffers in / out)
 // ---------------------------------------------------------------------------------------------------------------
-static int uploadImage(bhip_ctx* ctx, DevBuf& buf, const float* in, int start, int stride, int w, int h) {
-	BHIP_TRY(buf.reserve(ctx, (size_t)w * h * 4));
-	BHIP_HIP(ctx, hipMemcpy2DAsync(buf.p, (size_t)w * 4, in + start, (size_t)stride * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
+// pitch = floats between rows of the device copy (0: dense).  pitch4(w) keeps rows 16-byte aligned so the tiled ip kernels apply.
+static inline int pitch4(int w) { return (w + 3) & ~3; }
+static int uploadImage(bhip_ctx* ctx, DevBuf& buf, const float* in, int start, int stride, int w, int h, int pitch = 0) {
+	if (pitch == 0) pitch = w;
+	BHIP_TRY(buf.reserve(ctx, (size_t)pitch * h * 4));
+	BHIP_HIP(ctx, hipMemcpy2DAsync(buf.p, (size_t)pitch * 4, in + start, (size_t)stride * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
 	return BHIP_OK;
 }
-static int downloadImage(bhip_ctx* ctx, const void* dev, float* out, int start, int stride, int w, int h) {
-	BHIP_HIP(ctx, hipMemcpy2DAsync(out + start, (size_t)stride * 4, dev, (size_t)w * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost, ctx->stream));
+static int downloadImage(bhip_ctx* ctx, const void* dev, float* out, int start, int stride, int w, int h, int pitch = 0) {
+	if (pitch == 0) pitch = w;
+	BHIP_HIP(ctx, hipMemcpy2DAsync(out + start, (size_t)stride * 4, dev, (size_t)pitch * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;
 }
@@ -754,31 +742,51 @@ int bhip_hessian_f32(bhip_ctx* ctx, const float* ii, int iiStart, int iiStride, 
 	return downloadImage(ctx, sc->b.p, intensity, outStart, outStride, w, h);
 }
 
-int bhip_nonmax_block_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, int radius, float threshold,
-						  int border, int16_t* xy, int cap, int* n) {
-	CHECK_CTX(ctx);
-	CHECK_IMG(ctx, intensity, stride, width, height);
-	if (!n || cap < 0 || (cap > 0 && !xy)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad output");
+// strict block NMS of `batch` dense device images: lists into dev_xy ([batch][cap] (x,y) int16 pairs, block-raster order), counts into
+// dev_n[batch] (a count may exceed cap: only the first cap pairs are written)
+static int nonmaxDevice(bhip_ctx* ctx, const float* dev_intensity, long long imageStride, int stride, int width, int height, int batch, int radius,
+						float threshold, int border, int16_t* dev_xy, int cap, int* dev_n) {
 	if (radius < 1) return bhip_fail(ctx, BHIP_ERR_INVALID, "Search radius must be >= 1");
 	if (border < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Ignore border must be >= 0 ");
 	if (width >= 32768 || height >= 32768) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "image too large for Point2D_I16");
-	*n = 0;
+	BHIP_HIP(ctx, hipMemsetAsync(dev_n, 0, (size_t)batch * 4, ctx->stream));
 	const int step = radius + 1;
 	const int rw = width - 2 * border, rh = height - 2 * border;
 	if (rw <= 0 || rh <= 0) return BHIP_OK;
 	const int nbx = (rw + step - 1) / step, nby = (rh + step - 1) / step;
 	const int words = (int)(((long long)nbx * nby + 31) / 32) + 1;
 	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(sc->nmsBitmap.reserve(ctx, (size_t)words * 4 * batch));
+	BHIP_TRY(sc->nmsPrefix.reserve(ctx, (size_t)words * 4 * batch));
+	BHIP_TRY(sc->nmsPos.reserve(ctx, (size_t)nbx * nby * 2 * batch));
+	BHIP_HIP(ctx, hipMemsetAsync(sc->nmsBitmap.p, 0, (size_t)words * 4 * batch, ctx->stream));
+	BHIP_TRY(bhip_launch_nonmax_blocks(ctx, dev_intensity, imageStride, stride, width, height, batch, radius, threshold, border, sc->nmsBitmap.as<unsigned int>(),
+									   words, sc->nmsPos.as<unsigned short>(), nbx, nby));
+	BHIP_TRY(bhip_launch_word_prefix(ctx, sc->nmsBitmap.as<unsigned int>(), words, batch, sc->nmsPrefix.as<unsigned int>(), dev_n));
+	BHIP_TRY(bhip_launch_blocks_to_xy(ctx, sc->nmsBitmap.as<unsigned int>(), sc->nmsPrefix.as<unsigned int>(), words, sc->nmsPos.as<unsigned short>(), nbx, nby,
+									  batch, radius, border, dev_xy, cap));
+	return BHIP_OK;
+}
+
+int bhip_nonmax_block_dev_f32(bhip_ctx* ctx, const float* dev_intensity, long long imageStride, int stride, int width, int height, int batch, int radius,
+							  float threshold, int border, int16_t* dev_xy, int cap, int* dev_n) {
+	CHECK_CTX(ctx);
+	if (!dev_intensity || width <= 0 || height <= 0 || batch <= 0 || stride < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image batch");
+	if (!dev_n || cap < 0 || (cap > 0 && !dev_xy)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad output");
+	return nonmaxDevice(ctx, dev_intensity, imageStride, stride, width, height, batch, radius, threshold, border, dev_xy, cap, dev_n);
+}
+
+int bhip_nonmax_block_f32(bhip_ctx* ctx, const float* intensity, int start, int stride, int width, int height, int radius, float threshold,
+						  int border, int16_t* xy, int cap, int* n) {
+	CHECK_CTX(ctx);
+	CHECK_IMG(ctx, intensity, stride, width, height);
+	if (!n || cap < 0 || (cap > 0 && !xy)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad output");
+	*n = 0;
+	CtxScratch* sc = scratchOf(ctx);
 	BHIP_TRY(uploadImage(ctx, sc->a, intensity, start, stride, width, height));
-	BHIP_TRY(sc->b.reserve(ctx, (size_t)words * 4));
-	BHIP_TRY(sc->c.reserve(ctx, (size_t)words * 4));
 	BHIP_TRY(sc->d.reserve(ctx, 16));
 	BHIP_TRY(sc->e.reserve(ctx, (size_t)std::max(cap, 1) * 4));
-	BHIP_HIP(ctx, hipMemsetAsync(sc->b.p, 0, (size_t)words * 4, ctx->stream));
-	BHIP_TRY(bhip_launch_nonmax_only(ctx, sc->a.as<float>(), width, width, height, radius, threshold, border, sc->b.as<unsigned int>(), words, nbx, nby));
-	BHIP_TRY(bhip_launch_word_prefix(ctx, sc->b.as<unsigned int>(), words, 1, sc->c.as<unsigned int>(), sc->d.as<int>()));
-	BHIP_TRY(bhip_launch_bitmap_to_xy(ctx, sc->a.as<float>(), width, width, height, radius, threshold, border, sc->b.as<unsigned int>(),
-									  sc->c.as<unsigned int>(), words, nbx, nby, sc->e.as<int16_t>(), cap));
+	BHIP_TRY(nonmaxDevice(ctx, sc->a.as<float>(), 0, width, width, height, 1, radius, threshold, border, sc->e.as<int16_t>(), cap, sc->d.as<int>()));
 	BHIP_HIP(ctx, hipMemcpyAsync(ctx->hostScratch, sc->d.p, 4, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	*n = ctx->hostScratch[0];
@@ -1020,11 +1028,12 @@ static int convHost(bhip_ctx* ctx, bool vertical, bool normalized, const float* 
 	CHECK_IMG(ctx, out, outStride, width, height);
 	if (!kernel) return bhip_fail(ctx, BHIP_ERR_INVALID, "null kernel");
 	CtxScratch* sc = scratchOf(ctx);
-	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
+	const int pitch = pitch4(width);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height, pitch));
 	// the no-border variants leave the frame of `out` untouched: start from the caller's pixels
-	BHIP_TRY(uploadImage(ctx, sc->b, out, outStart, outStride, width, height));
-	BHIP_TRY(bhip_launch_conv(ctx, vertical, normalized, kernel, kw, koff, sc->a.as<float>(), width, width, height, sc->b.as<float>(), width));
-	return downloadImage(ctx, sc->b.p, out, outStart, outStride, width, height);
+	BHIP_TRY(uploadImage(ctx, sc->b, out, outStart, outStride, width, height, pitch));
+	BHIP_TRY(bhip_launch_conv(ctx, vertical, normalized, kernel, kw, koff, sc->a.as<float>(), pitch, width, height, sc->b.as<float>(), pitch));
+	return downloadImage(ctx, sc->b.p, out, outStart, outStride, width, height, pitch);
 }
 int bhip_conv_h_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStart, int inStride, int width, int height, float* out,
 					int outStart, int outStride) {
@@ -1056,12 +1065,13 @@ int bhip_gaussian_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride,
 	std::vector<float> k = bhip_gaussian1d_f32(sigma, radius);
 	const int kw = (int)k.size(), koff = kw / 2;
 	CtxScratch* sc = scratchOf(ctx);
-	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
-	BHIP_TRY(sc->b.reserve(ctx, (size_t)width * height * 4));
-	BHIP_TRY(sc->c.reserve(ctx, (size_t)width * height * 4));
-	BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, sc->a.as<float>(), width, width, height, sc->b.as<float>(), width));
-	BHIP_TRY(bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->b.as<float>(), width, width, height, sc->c.as<float>(), width));
-	return downloadImage(ctx, sc->c.p, out, outStart, outStride, width, height);
+	const int pitch = pitch4(width);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height, pitch));
+	BHIP_TRY(sc->b.reserve(ctx, (size_t)pitch * height * 4));
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)pitch * height * 4));
+	BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, sc->a.as<float>(), pitch, width, height, sc->b.as<float>(), pitch));
+	BHIP_TRY(bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->b.as<float>(), pitch, width, height, sc->c.as<float>(), pitch));
+	return downloadImage(ctx, sc->c.p, out, outStart, outStride, width, height, pitch);
 }
 
 static int convDownHost(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, int inStart, int inStride, int width, int height,
@@ -1233,12 +1243,13 @@ static int gradHost(bhip_ctx* ctx, int kind, const float* in, int inStart, int i
 	CHECK_IMG(ctx, dy, outStride, width, height);
 	if (border != 0 && border != 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "border policy not supported on the GPU");
 	CtxScratch* sc = scratchOf(ctx);
-	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height));
-	BHIP_TRY(uploadImage(ctx, sc->b, dx, outStart, outStride, width, height));
-	BHIP_TRY(uploadImage(ctx, sc->c, dy, outStart, outStride, width, height));
-	BHIP_TRY(bhip_launch_gradient(ctx, kind, sc->a.as<float>(), width, width, height, sc->b.as<float>(), sc->c.as<float>(), width, border));
-	BHIP_TRY(downloadImage(ctx, sc->b.p, dx, outStart, outStride, width, height));
-	return downloadImage(ctx, sc->c.p, dy, outStart, outStride, width, height);
+	const int pitch = pitch4(width);
+	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height, pitch));
+	BHIP_TRY(uploadImage(ctx, sc->b, dx, outStart, outStride, width, height, pitch));
+	BHIP_TRY(uploadImage(ctx, sc->c, dy, outStart, outStride, width, height, pitch));
+	BHIP_TRY(bhip_launch_gradient(ctx, kind, sc->a.as<float>(), pitch, width, height, sc->b.as<float>(), sc->c.as<float>(), pitch, border));
+	BHIP_TRY(downloadImage(ctx, sc->b.p, dx, outStart, outStride, width, height, pitch));
+	return downloadImage(ctx, sc->c.p, dy, outStart, outStride, width, height, pitch);
 }
 int bhip_sobel_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride, int width, int height, float* dx, float* dy, int outStart, int outStride,
 				   int border) {
@@ -1344,6 +1355,138 @@ int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int w
 	BHIP_TRY(bhip_launch_brief(ctx, sc->a.as<float>(), width, width, height, radius, numPoints, dsp, dcp, sc->c.as<double>(), n, sc->e.as<int>()));
 	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->e.p, (size_t)n * words * 4, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-resident, batched forms of the boofcv-ip front end (BASELINE config 5: pyramid -> gradient -> NMS -> SURF on a 4K stream without
+// leaving HBM).  Image b of a batch starts imageStride floats after image 0, rows are `stride` floats apart; everything is
+// asynchronous on the ctx stream.  Same kernels and arithmetic as the host-buffer entry points above.
+// ---------------------------------------------------------------------------------------------------------------
+#define CHECK_DEV_BATCH(ctx, p, stride, w, h, batch)                                                                                      \
+	do {                                                                                                                                  \
+		if (!(p) || (w) <= 0 || (h) <= 0 || (batch) <= 0 || (stride) < (w)) return bhip_fail((ctx), BHIP_ERR_INVALID, "bad image batch"); \
+	} while (0)
+
+static int convDev(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* dev_in, long long inImageStride,
+				   int inStride, int width, int height, int batch, float* dev_out, long long outImageStride, int outStride) {
+	CHECK_DEV_BATCH(ctx, dev_in, inStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_out, outStride, width, height, batch);
+	if (!kernel) return bhip_fail(ctx, BHIP_ERR_INVALID, "null kernel");
+	return bhip_launch_conv(ctx, vertical, normalized, kernel, kw, koff, dev_in, inStride, width, height, dev_out, outStride, batch, inImageStride, outImageStride);
+}
+int bhip_conv_h_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* dev_in, long long inImageStride, int inStride, int width, int height,
+						int batch, float* dev_out, long long outImageStride, int outStride) {
+	CHECK_CTX(ctx);
+	return convDev(ctx, false, false, kernel, kw, koff, dev_in, inImageStride, inStride, width, height, batch, dev_out, outImageStride, outStride);
+}
+int bhip_conv_v_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* dev_in, long long inImageStride, int inStride, int width, int height,
+						int batch, float* dev_out, long long outImageStride, int outStride) {
+	CHECK_CTX(ctx);
+	return convDev(ctx, true, false, kernel, kw, koff, dev_in, inImageStride, inStride, width, height, batch, dev_out, outImageStride, outStride);
+}
+int bhip_conv_norm_h_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* dev_in, long long inImageStride, int inStride, int width,
+							 int height, int batch, float* dev_out, long long outImageStride, int outStride) {
+	CHECK_CTX(ctx);
+	return convDev(ctx, false, true, kernel, kw, koff, dev_in, inImageStride, inStride, width, height, batch, dev_out, outImageStride, outStride);
+}
+int bhip_conv_norm_v_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* dev_in, long long inImageStride, int inStride, int width,
+							 int height, int batch, float* dev_out, long long outImageStride, int outStride) {
+	CHECK_CTX(ctx);
+	return convDev(ctx, true, true, kernel, kw, koff, dev_in, inImageStride, inStride, width, height, batch, dev_out, outImageStride, outStride);
+}
+
+// BlurImageOps.gaussian on a device batch: horizontal pass into the library's `storage`, vertical pass into dev_out
+int bhip_gaussian_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, double sigma, int radius,
+						  float* dev_out, long long outImageStride, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_DEV_BATCH(ctx, dev_in, inStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_out, outStride, width, height, batch);
+	if (sigma <= 0 && radius <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "Sigma must be > 0");
+	std::vector<float> k = bhip_gaussian1d_f32(sigma, radius);
+	const int kw = (int)k.size(), koff = kw / 2;
+	CtxScratch* sc = scratchOf(ctx);
+	const int pitch = pitch4(width);
+	const long long tmpImage = (long long)pitch * height;
+	BHIP_TRY(sc->ipTmp.reserve(ctx, (size_t)tmpImage * 4 * batch));
+	BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, dev_in, inStride, width, height, sc->ipTmp.as<float>(), pitch, batch, inImageStride, tmpImage));
+	return bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->ipTmp.as<float>(), pitch, width, height, dev_out, outStride, batch, tmpImage, outImageStride);
+}
+
+static int gradDev(bhip_ctx* ctx, int kind, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, float* dev_dx,
+				   float* dev_dy, long long outImageStride, int outStride, int border) {
+	CHECK_DEV_BATCH(ctx, dev_in, inStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_dx, outStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_dy, outStride, width, height, batch);
+	if (border != 0 && border != 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "border policy not supported on the GPU");
+	return bhip_launch_gradient(ctx, kind, dev_in, inStride, width, height, dev_dx, dev_dy, outStride, border, batch, inImageStride, outImageStride);
+}
+int bhip_sobel_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, float* dev_dx, float* dev_dy,
+					   long long outImageStride, int outStride, int border) {
+	CHECK_CTX(ctx);
+	return gradDev(ctx, 0, dev_in, inImageStride, inStride, width, height, batch, dev_dx, dev_dy, outImageStride, outStride, border);
+}
+int bhip_three_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, float* dev_dx, float* dev_dy,
+					   long long outImageStride, int outStride, int border) {
+	CHECK_CTX(ctx);
+	return gradDev(ctx, 1, dev_in, inImageStride, inStride, width, height, batch, dev_dx, dev_dy, outImageStride, outStride, border);
+}
+
+int bhip_gradient_intensity_dev_f32(bhip_ctx* ctx, int kind, const float* dev_dx, const float* dev_dy, long long dImageStride, int dStride, int width, int height,
+									int batch, float* dev_out, long long outImageStride, int outStride) {
+	CHECK_CTX(ctx);
+	CHECK_DEV_BATCH(ctx, dev_dx, dStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_dy, dStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_out, outStride, width, height, batch);
+	return bhip_launch_grad_intensity(ctx, kind, dev_dx, dev_dy, dImageStride, dStride, dev_out, outImageStride, outStride, width, height, batch);
+}
+
+int bhip_corner_intensity_dev_f32(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dev_dx, const float* dev_dy, long long dImageStride, int dStride,
+								  int width, int height, int batch, float* dev_intensity, long long iImageStride, int iStride) {
+	CHECK_CTX(ctx);
+	CHECK_DEV_BATCH(ctx, dev_dx, dStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_dy, dStride, width, height, batch);
+	CHECK_DEV_BATCH(ctx, dev_intensity, iStride, width, height, batch);
+	CtxScratch* sc = scratchOf(ctx);
+	const size_t px = (size_t)width * height;
+	BHIP_TRY(sc->ipTmp.reserve(ctx, px * 4 * 3 * batch));
+	// ImageMiscOps.fillBorder(intensity, 0, radius): clear every image, the interior is overwritten
+	BHIP_HIP(ctx, hipMemset2DAsync(dev_intensity, (size_t)iStride * 4, 0, (size_t)width * 4, (size_t)height, ctx->stream));
+	for (int b = 1; b < batch; b++)
+		BHIP_HIP(ctx, hipMemset2DAsync(dev_intensity + (long long)b * iImageStride, (size_t)iStride * 4, 0, (size_t)width * 4, (size_t)height, ctx->stream));
+	float* h = sc->ipTmp.as<float>();
+	return bhip_launch_corner_intensity(ctx, kind, radius, kappa, dev_dx, dev_dy, dStride, width, height, h, h + px, h + 2 * px, dev_intensity, iStride, batch,
+										dImageStride, (long long)px * 3, iImageStride);
+}
+
+// DescribePointBrief.process over a batch: the points of image b are dev_xy[start[b] .. start[b+1]) (host prefix `start`, batch+1 entries);
+// words of point p at dev_out[p * ceil(numPoints/32)]
+int bhip_brief_dev_f32(bhip_ctx* ctx, const float* dev_img, long long imageStride, int stride, int width, int height, int batch, int radius, int numPoints,
+					   const int32_t* samplePoints, const int32_t* compare, const double* dev_xy, const int* start, int32_t* dev_out) {
+	CHECK_CTX(ctx);
+	CHECK_DEV_BATCH(ctx, dev_img, stride, width, height, batch);
+	if (numPoints <= 0 || !samplePoints || !compare || !start) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad BRIEF arguments");
+	int maxCount = 0;
+	for (int b = 0; b < batch; b++) {
+		if (start[b + 1] < start[b]) return bhip_fail(ctx, BHIP_ERR_INVALID, "point prefix must not decrease");
+		maxCount = std::max(maxCount, start[b + 1] - start[b]);
+	}
+	const int n = start[batch] - start[0];
+	if (n == 0) return BHIP_OK;
+	if (!dev_xy || !dev_out) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad BRIEF arguments");
+	int maxIdx = 0;
+	for (int i = 0; i < 2 * numPoints; i++) { if (compare[i] < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "negative sample index"); maxIdx = std::max(maxIdx, compare[i]); }
+	CtxScratch* sc = scratchOf(ctx);
+	const size_t nSample = (size_t)(maxIdx + 1) * 2, nCompare = (size_t)numPoints * 2;
+	BHIP_TRY(sc->ipKernel.reserve(ctx, (nSample + nCompare + batch + 1) * 4));
+	int* dSample = sc->ipKernel.as<int>();
+	int* dCompare = dSample + nSample;
+	int* dStart = dCompare + nCompare;
+	BHIP_HIP(ctx, hipMemcpyAsync(dSample, samplePoints, nSample * 4, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(dCompare, compare, nCompare * 4, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(dStart, start, (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_TRY(bhip_launch_brief(ctx, dev_img, stride, width, height, radius, numPoints, dSample, dCompare, dev_xy, n, dev_out, false, batch, imageStride, dStart, maxCount));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host tables were handed to async copies
 	return BHIP_OK;
 }
 

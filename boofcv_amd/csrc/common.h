@@ -4,12 +4,27 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <new>
 #include "../../include/boofhip.h"
 
 #define BHIP_WAVE 64
+
+// Parity cross-check hooks (BHIP_DETECT_UNFUSED, BHIP_ASSOC_EXACT, ...) select an alternative, equally exact execution plan; they are read
+// from the environment on every call (no process-wide cache: contexts on different host threads may not share mutable statics).
+// Timing-experiment switches (ablation, tile variants, stamps) exist only in -DBHIP_EXPERIMENTS builds (boofcv_amd/build.py --experiments),
+// never in the shipped libboofhip.so.
+static inline bool bhip_env_flag(const char* name) {
+	const char* e = getenv(name);
+	return e && e[0] == '1';
+}
+#ifdef BHIP_EXPERIMENTS
+#define BHIP_ABLATE(P, bits) ((P).ablate & (bits))
+#else
+#define BHIP_ABLATE(P, bits) 0
+#endif
 
 // one bracketed kernel launch (profiling mode only)
 struct ProfRecord {
@@ -30,6 +45,7 @@ struct bhip_ctx {
 	bool profiling = false;
 	std::vector<ProfRecord> profRecords;
 	std::vector<hipEvent_t> eventPool;
+	size_t integralLdsAttr = 0;   // largest dynamic-LDS size k_integral_fused has been configured for on this ctx's device
 };
 
 // RAII bracket around one kernel launch: records a start/stop event pair on the ctx stream when profiling is on
@@ -39,6 +55,8 @@ struct ProfScope {
 	ProfScope(bhip_ctx* c, const char* tag, double algBytes = 0, double algFlops = 0);
 	~ProfScope();
 };
+
+void bhip_profile_release(bhip_ctx* ctx);   // destroys the ctx's profiling events (profile.hip)
 
 static inline int bhip_fail(bhip_ctx* ctx, int code, const std::string& msg) {
 	if (ctx) ctx->error = msg;
@@ -178,10 +196,6 @@ int bhip_launch_compact_levels(bhip_ctx* ctx, const KeyPoint* src, int cap, cons
 							   int* totals);
 int bhip_launch_rank_scatter(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, unsigned int* wordPrefix, const KeyPoint* cand,
 							 const int* candCount, int cap, int batch, KeyPoint* sorted);
-int bhip_launch_nonmax_only(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border, unsigned int* bitmap,
-							int bitmapWords, int nbx, int nby);
-int bhip_launch_bitmap_to_xy(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border,
-							 const unsigned int* bitmap, const unsigned int* wordPrefix, int bitmapWords, int nbx, int nby, int16_t* xy, int cap);
 int bhip_launch_word_prefix(bhip_ctx* ctx, const unsigned int* bitmap, int bitmapWords, int batch, unsigned int* wordPrefix, int* totals);
 
 int bhip_launch_describe(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, const int* kpImage /*may be null: use imageOfBlock*/, long long total,
@@ -191,3 +205,29 @@ int bhip_launch_assoc_l2(bhip_ctx* ctx, const double* src, int ns, const double*
 						 int* pairs, double* fit, DevBuf& work);
 int bhip_launch_assoc_hamming(bhip_ctx* ctx, const int32_t* src, int ns, const int32_t* dst, int nd, int words, double maxErr, int backwards,
 							  int* pairs, double* fit, DevBuf& work);
+
+// ---------------- boofcv-ip front end (ip.hip); device images, `batch` of them imageStride floats apart ----------------
+int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
+					 int height, float* out, int outStride, int batch = 1, long long inImageStride = 0, long long outImageStride = 0);
+int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
+						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch);
+int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out);
+int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dx, const float* dy, int dStride, int width, int height,
+								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride, int batch = 1, long long dImageStride = 0,
+								 long long hImageStride = 0, long long iImageStride = 0);
+int bhip_launch_conv2d(bhip_ctx* ctx, const float* kernel, int kw, int koff, const float* in, int inStride, int width, int height, float* out, int outStride);
+int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, int width, int height, int radius);
+int bhip_launch_median(bhip_ctx* ctx, const float* in, int inStride, float* out, int outStride, int width, int height, int radius);
+int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border,
+						 int batch = 1, long long inImageStride = 0, long long outImageStride = 0);
+int bhip_launch_grad_intensity(bhip_ctx* ctx, int kind, const float* dx, const float* dy, long long dImageStride, int dStride, float* out,
+							   long long oImageStride, int oStride, int width, int height, int batch);
+int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
+					  const int* compare, const double* xy, int n, int* out, bool u8 = false, int batch = 1, long long imageStride = 0,
+					  const int* start = nullptr, int maxCount = 0);
+// stand-alone strict block NMS over a batch (detect.hip): bitmap of accepted blocks + the pixel's position inside its block
+int bhip_launch_nonmax_blocks(bhip_ctx* ctx, const float* img, long long imageStride, int stride, int w, int h, int batch, int radius, float threshold, int border,
+							  unsigned int* bitmap, int bitmapWords, unsigned short* posInBlock, int nbx, int nby);
+int bhip_launch_blocks_to_xy(bhip_ctx* ctx, const unsigned int* bitmap, const unsigned int* wordPrefix, int bitmapWords, const unsigned short* posInBlock,
+							 int nbx, int nby, int batch, int radius, int border, int16_t* xy, int cap);
+

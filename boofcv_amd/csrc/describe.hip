@@ -912,20 +912,21 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	}
 	P.ldsPerWave = bhip_describe_lds_bytes(t, P.nBands);
 	P.stamps = nullptr;
-	{ const char* e = getenv("BHIP_DESCRIBE_SERIAL"); P.serialOnly = (e && e[0] == '1') ? 1 : 0; }
-	{ const char* e = getenv("BHIP_DESCRIBE_SORT64"); P.sort64 = (e && e[0] == '1') ? 1 : 0; }
+	P.serialOnly = bhip_env_flag("BHIP_DESCRIBE_SERIAL") ? 1 : 0;   // parity cross-checks of the two window sweeps / the two sort keys
+	P.sort64 = bhip_env_flag("BHIP_DESCRIBE_SORT64") ? 1 : 0;
 	if (t.oriWidth * t.oriWidth > 64 * ORI_EPL_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation sample grid too large for the GPU path");
 	if (t.widthSubRegion + 2 * (t.stable ? t.overLap : 0) > DESC_ROW_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "SURF sub-region too wide for the GPU path");
 	if (P.ldsPerWave * 4 > 160 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation/descriptor sample grid too large for LDS");
 	const long long blocks = ((((total + 3) / 4) + 7) / 8) * 8;   // whole rounds over the 8 XCDs
 	if (blocks > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_INVALID, "too many key points");
 	if ((long long)ii.stride * ii.height > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "integral image too large for 32-bit tap offsets");
+#ifdef BHIP_EXPERIMENTS
 	const char* stampPath = getenv("BHIP_DESCRIBE_STAMPS");
-	if (stampPath && total > 1000) {
+	if (stampPath && total > 1000 && !(planar && planar->intTaps)) {
 		// diagnostic build: phase shares of the describe kernel (never a quoted run time)
 		unsigned long long* dev = nullptr;
 		if (hipMalloc(&dev, (size_t)total * 128) == hipSuccess) {
-			(void)hipMemsetAsync(dev, 0, (size_t)total * 64, ctx->stream);
+			(void)hipMemsetAsync(dev, 0, (size_t)total * 128, ctx->stream);
 			P.stamps = dev;
 			{
 				const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
@@ -934,7 +935,8 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 				else hipLaunchKernelGGL((k_describe<true, 8, 16, float>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 			}
 			std::vector<unsigned long long> h((size_t)total * 16);
-			(void)hipMemcpy(h.data(), dev, (size_t)total * 64, hipMemcpyDeviceToHost);
+			(void)hipMemcpyAsync(h.data(), dev, (size_t)total * 128, hipMemcpyDeviceToHost, ctx->stream);
+			(void)hipStreamSynchronize(ctx->stream);
 			(void)hipFree(dev);
 			double sum[7] = {0}, wsum[6] = {0};
 			long long cnt = 0;
@@ -957,6 +959,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 			return BHIP_OK;
 		}
 	}
+#endif
 	{
 		// per key point: every orientation and descriptor sample reads 12 integral-image taps; angle + descriptor + sign written once
 		const int gridWv = t.widthLargeGrid * t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
@@ -967,7 +970,16 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 		const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
 		const dim3 grid((unsigned)blocks), block(256);
 		size_t ldsBytes = (size_t)P.ldsPerWave * 4;
+#ifdef BHIP_EXPERIMENTS
 		{ const char* e = getenv("BHIP_DESCRIBE_LDSPAD"); if (e) ldsBytes += (size_t)atoi(e); }   // occupancy experiments only
+#endif
+		// colour SURF with many bands / large sample grids need more than the default 64 KB of dynamic LDS
+		if (ldsBytes > 65536) {
+			const void* fn = nullptr;
+			if (planar && planar->intTaps) fn = (epl == 5 && tw == 9) ? (const void*)k_describe<false, 5, 9, int> : (epl == 3 && tw == 5) ? (const void*)k_describe<false, 3, 5, int> : (const void*)k_describe<false, 8, 16, int>;
+			else fn = (epl == 5 && tw == 9) ? (const void*)k_describe<false, 5, 9, float> : (epl == 3 && tw == 5) ? (const void*)k_describe<false, 3, 5, float> : (const void*)k_describe<false, 8, 16, float>;
+			BHIP_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+		}
 		if (planar && planar->intTaps) {   // GrayS32 integral image(s)
 			if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9, int>), grid, block, ldsBytes, ctx->stream, P);
 			else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5, int>), grid, block, ldsBytes, ctx->stream, P);

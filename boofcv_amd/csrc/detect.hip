@@ -442,56 +442,110 @@ int bhip_launch_select_nbest_xy(bhip_ctx* ctx, const float* img, int stride, con
 	return BHIP_OK;
 }
 
-// ---- stand-alone NMS (BOverrideFactoryFeatureExtractor.nonmax / parity tests) ----
-__global__ __launch_bounds__(256) void k_nonmax_only(const float* __restrict__ img, int stride, int w, int h, int radius, float thr, int border,
-													  unsigned int* __restrict__ bitmap, int nbx) {
-	const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = border + blockIdx.y;
-	if (x >= w - border || y >= h - border) return;
-	const float v = img[(long long)y * stride + x];
-	if (!strictLocalMax<0>(img, stride, w, h, x, y, radius, v, thr)) return;
-	const int step = radius + 1;
-	const unsigned int bit = (unsigned)((y - border) / step) * (unsigned)nbx + (unsigned)((x - border) / step);
-	atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+// ---- stand-alone NMS over a batch of intensity images (BOverrideFactoryFeatureExtractor.nonmax, GeneralFeatureDetector, config-5 chain) ----
+// Same structure as k_nms_scalespace: NMS_ROWS rows per thread, a cheap four-neighbour test, survivors compacted per block and tested
+// densely.  An accepted pixel sets the bit of its (r+1)^2 block (at most one pixel per block can pass) and records its position inside the
+// block, so the ordered list is rebuilt from the bitmap alone (k_blocks_to_xy) without a second pass over the image.
+struct NonmaxParams {
+	const float* img;
+	long long imageStride;
+	int stride, w, h, radius, border, nbx, bitmapWords;
+	float threshold;
+	unsigned int* bitmap;          // [batch][bitmapWords]
+	unsigned short* posInBlock;    // [batch][nbx*nby]
+	long long blocksPerImage;
+};
+__global__ __launch_bounds__(256) void k_nonmax_blocks(NonmaxParams P) {
+	const int b = P.border, w = P.w, h = P.h, r = P.radius, stride = P.stride;
+	const int x = b + blockIdx.x * blockDim.x + threadIdx.x;
+	const int yBase = b + blockIdx.y * NMS_ROWS;
+	const float* img = P.img + (long long)blockIdx.z * P.imageStride;
+	float col[NMS_ROWS + 2], lf[NMS_ROWS], rt[NMS_ROWS];
+#pragma unroll
+	for (int k = 0; k < NMS_ROWS + 2; k++) {
+		const int yy = yBase - 1 + k;
+		col[k] = (yy >= 0 && yy < h && x < w - b) ? img[(long long)yy * stride + x] : -INFINITY;
+	}
+#pragma unroll
+	for (int k = 0; k < NMS_ROWS; k++) {
+		const int yy = yBase + k;
+		const bool rowIn = yy < h && x < w - b;
+		lf[k] = (rowIn && x >= 1) ? img[(long long)yy * stride + x - 1] : -INFINITY;
+		rt[k] = (rowIn && x + 1 < w) ? img[(long long)yy * stride + x + 1] : -INFINITY;
+	}
+	__shared__ int candList[256 * NMS_ROWS];
+	__shared__ int candCount;
+	if (threadIdx.x == 0) candCount = 0;
+	__syncthreads();
+	if (x < w - b) {
+#pragma unroll
+		for (int k = 0; k < NMS_ROWS; k++) {
+			const int y = yBase + k;
+			const float val = col[k + 1];
+			const bool pass = y < h - b && val >= P.threshold && val != FLT_MAX && !(lf[k] >= val || rt[k] >= val || col[k] >= val || col[k + 2] >= val);
+			if (pass) candList[atomicAdd(&candCount, 1)] = (k << 16) | (int)threadIdx.x;
+		}
+	}
+	__syncthreads();
+	const int ncand = candCount;
+	const int step = r + 1;
+	for (int ci = threadIdx.x; ci < ncand; ci += blockDim.x) {
+		const int code = candList[ci];
+		const int cx = b + blockIdx.x * blockDim.x + (code & 0xFFFF);
+		const int cy = yBase + (code >> 16);
+		const float val = img[(long long)cy * stride + cx];
+		if (!(r == 2 ? strictLocalMax<2>(img, stride, w, h, cx, cy, r, val, P.threshold) : strictLocalMax<0>(img, stride, w, h, cx, cy, r, val, P.threshold))) continue;
+		const int bx = (cx - b) / step, by = (cy - b) / step;
+		const unsigned int bit = (unsigned)by * (unsigned)P.nbx + (unsigned)bx;
+		atomicOr(&P.bitmap[(long long)blockIdx.z * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+		P.posInBlock[(long long)blockIdx.z * P.blocksPerImage + bit] = (unsigned short)((cy - b - by * step) * step + (cx - b - bx * step));
+	}
 }
 
-int bhip_launch_nonmax_only(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border, unsigned int* bitmap,
-							int bitmapWords, int nbx, int nby) {
-	(void)bitmapWords; (void)nby;
+int bhip_launch_nonmax_blocks(bhip_ctx* ctx, const float* img, long long imageStride, int stride, int w, int h, int batch, int radius, float threshold, int border,
+							  unsigned int* bitmap, int bitmapWords, unsigned short* posInBlock, int nbx, int nby) {
 	const int rw = w - 2 * border, rh = h - 2 * border;
-	if (rw <= 0 || rh <= 0) return BHIP_OK;
-	dim3 grid((rw + 255) / 256, rh);
-	hipLaunchKernelGGL(k_nonmax_only, grid, dim3(256), 0, ctx->stream, img, stride, w, h, radius, threshold, border, bitmap, nbx);
+	if (rw <= 0 || rh <= 0 || batch <= 0) return BHIP_OK;
+	if (radius > 254) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "NMS radius too large");
+	NonmaxParams P{img, imageStride, stride, w, h, radius, border, nbx, bitmapWords, threshold, bitmap, posInBlock, (long long)nbx * nby};
+	dim3 grid((rw + 255) / 256, (rh + NMS_ROWS - 1) / NMS_ROWS, batch);
+	{
+		ProfScope ps(ctx, "k_nonmax_blocks", 4.0 * w * h * batch);
+		hipLaunchKernelGGL(k_nonmax_blocks, grid, dim3(256), 0, ctx->stream, P);
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
 
-// second pass of the stand-alone NMS: every accepted pixel writes its (x,y) at its block-raster rank
-__global__ __launch_bounds__(256) void k_bitmap_to_xy(const float* __restrict__ img, int stride, int w, int h, int radius, float thr, int border,
-													   const unsigned int* __restrict__ bitmap, const unsigned int* __restrict__ prefix, int nbx,
+// one thread per bitmap word: every set bit (= accepted block, ascending = block-raster order) writes (x,y) at its rank
+__global__ __launch_bounds__(256) void k_blocks_to_xy(const unsigned int* __restrict__ bitmap, const unsigned int* __restrict__ prefix, int words,
+													   const unsigned short* __restrict__ posInBlock, long long blocksPerImage, int nbx, int step, int border,
 													   int16_t* __restrict__ xy, int cap) {
-	const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = border + blockIdx.y;
-	if (x >= w - border || y >= h - border) return;
-	const float v = img[(long long)y * stride + x];
-	if (!strictLocalMax<0>(img, stride, w, h, x, y, radius, v, thr)) return;
-	const int step = radius + 1;
-	const unsigned int bit = (unsigned)((y - border) / step) * (unsigned)nbx + (unsigned)((x - border) / step);
-	const unsigned int word = bit >> 5;
-	const unsigned int rank = prefix[word] + __popc(bitmap[word] & ((1u << (bit & 31)) - 1u));
-	if ((int)rank < cap) {
-		xy[2 * rank] = (int16_t)x;
-		xy[2 * rank + 1] = (int16_t)y;
+	const int word = blockIdx.x * blockDim.x + threadIdx.x;
+	if (word >= words) return;
+	const long long img = blockIdx.y;
+	unsigned int bits = bitmap[img * words + word];
+	unsigned int rank = prefix[img * words + word];
+	while (bits) {
+		const int bit = __ffs(bits) - 1;
+		bits &= bits - 1;
+		const long long idx = (long long)word * 32 + bit;
+		const int by = (int)(idx / nbx), bx = (int)(idx - (long long)by * nbx);
+		const int pos = posInBlock[img * blocksPerImage + idx];
+		if ((int)rank < cap) {
+			xy[(img * cap + rank) * 2] = (int16_t)(border + bx * step + pos % step);
+			xy[(img * cap + rank) * 2 + 1] = (int16_t)(border + by * step + pos / step);
+		}
+		rank++;
 	}
 }
 
-int bhip_launch_bitmap_to_xy(bhip_ctx* ctx, const float* img, int stride, int w, int h, int radius, float threshold, int border,
-							 const unsigned int* bitmap, const unsigned int* wordPrefix, int bitmapWords, int nbx, int nby, int16_t* xy, int cap) {
-	(void)bitmapWords; (void)nby;
-	const int rw = w - 2 * border, rh = h - 2 * border;
-	if (rw <= 0 || rh <= 0) return BHIP_OK;
-	dim3 grid((rw + 255) / 256, rh);
-	hipLaunchKernelGGL(k_bitmap_to_xy, grid, dim3(256), 0, ctx->stream, img, stride, w, h, radius, threshold, border, bitmap, wordPrefix, nbx, xy, cap);
+int bhip_launch_blocks_to_xy(bhip_ctx* ctx, const unsigned int* bitmap, const unsigned int* wordPrefix, int bitmapWords, const unsigned short* posInBlock,
+							 int nbx, int nby, int batch, int radius, int border, int16_t* xy, int cap) {
+	if (batch <= 0 || bitmapWords <= 0 || cap <= 0) return BHIP_OK;
+	ProfScope ps(ctx, "k_blocks_to_xy");
+	hipLaunchKernelGGL(k_blocks_to_xy, dim3((bitmapWords + 255) / 256, batch), dim3(256), 0, ctx->stream, bitmap, wordPrefix, bitmapWords, posInBlock,
+					   (long long)nbx * nby, nbx, radius + 1, border, xy, cap);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }

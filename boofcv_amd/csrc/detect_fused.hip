@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(FusedParams P) {
 	const int X0 = (x0 - P.HR) * s - P.rFmax - 1, Y0 = (y0 - P.HR) * s - P.rFmax - 1;
 
 	// ---- stage the integral-image patch (rows of IW floats, coalesced)
-	if (!(P.ablate & 4)) {
+	if (!BHIP_ABLATE(P, 4)) {
 		const int tx = tid & 63, ty = tid >> 6;
 		for (int ry = ty; ry < P.IH; ry += 4) {
 			const int gy = Y0 + ry;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(FusedParams P) {
 
 	// ---- intensity of every level over the tile + halo
 	const int itemsPerLevel = P.ITH << P.ITWlog;
-	for (int L = 0; L < ((P.ablate & 1) ? 0 : P.nlevels); L++) {
+	for (int L = 0; L < (BHIP_ABLATE(P, 1) ? 0 : P.nlevels); L++) {
 		const FusedLevel V = P.lv[L];
 		float* out = inten + (size_t)L * P.ITH * P.ITp;
 		// tap offsets inside the patch, relative to (xx - X0, yy - Y0)
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(FusedParams P) {
 	// ---- strict (2r+1)^2 maximum + scale-space test on the mid levels, from LDS
 	const int r = P.radius;
 	const int wave = tid >> 6, lane = tid & 63;
-	const int rows = (P.ablate & 2) ? 0 : P.nmid * P.TY;
+	const int rows = BHIP_ABLATE(P, 2) ? 0 : P.nmid * P.TY;
 	for (int row = wave; row < rows; row += 4) {
 		const int m = row / P.TY;
 		const int py = row - m * P.TY;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		// the patch origin is an even column, so with an even row stride every row of the patch is a run of aligned float2 -- half the load
 		// instructions of the scalar path below (this kernel is bound by staging: ~9 k floats per tile); the two halves of a pair go to the two
 		// column-phase planes at the same index
-		if (!(P.ablate & 4) && (stride & 1) == 0 && (W & 1) == 0 && (((unsigned long long)d) & 7ull) == 0) {
+		if (!BHIP_ABLATE(P, 4) && (stride & 1) == 0 && (W & 1) == 0 && (((unsigned long long)d) & 7ull) == 0) {
 			const int tx = tid & 63, ty = tid >> 6;
 			constexpr int PAIRS = G::IW / 2;
 			static_assert(PAIRS <= 64, "one lane per float2 of a patch row");
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			staged = true;
 		}
 	}
-	if (!staged && !(P.ablate & 4)) {
+	if (!staged && !BHIP_ABLATE(P, 4)) {
 		// stage the patch: every thread keeps a batch of independent global loads in flight before the first LDS store
 		const int tx = tid & 63, ty = tid >> 6;
 		constexpr int COLS = (G::IW + 63) / 64;   // 64-float column chunks per row
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		}
 	}
 	__syncthreads();
-	if (!(P.ablate & 1)) fusedLevelFixed<G, SKIP, NL, R, 0, T>(P, iiT, inten, tid, x0, y0, X0, Y0);
+	if (!BHIP_ABLATE(P, 1)) fusedLevelFixed<G, SKIP, NL, R, 0, T>(P, iiT, inten, tid, x0, y0, X0, Y0);
 	__syncthreads();
 	if (P.nexp > 0) {
 		// even pixels of the tile core -> pixel (x/2, y/2) of the next octave
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	}
 
 	// candidates: ITW-wide rows of lanes (ITW <= 64 is a power of two), so a wave covers 64 / ITW tile rows per pass
-	const int rows = (P.ablate & 2) ? 0 : P.nmid * G::TY;
+	const int rows = BHIP_ABLATE(P, 2) ? 0 : P.nmid * G::TY;
 	for (int it = tid; it < rows * G::ITW; it += 256) {
 		const int row = it / G::ITW;
 		const int px = it & (G::ITW - 1);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		const float interpS = (float)M.sizeMid + peakS * (float)(M.sizeMid - M.sizeLower);
 		const double scale = 1.2 * (double)interpS / 9.0;
 		constexpr int step = R + 1;
-		if (P.ablate & 7) continue;   // timing experiments run on garbage: never emit
+		if (BHIP_ABLATE(P, 7)) continue;   // timing experiments run on garbage: never emit
 		const unsigned int bit = M.bitBase + (unsigned)((y - b) / step) * (unsigned)M.nbx + (unsigned)((x - b) / step);
 		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
 		const int slot = atomicAdd(&P.candCount[img], 1);
@@ -635,7 +635,9 @@ bool bhip_fused_plan(int skip, int nlevels, const int* sizes, int radius, int* T
 // true when the octave runs on the compile-time-geometry kernel (the only fused kernel that can export levels)
 bool bhip_fused_is_fixed(int skip, int nlevels, const int* sizes, int radius) {
 	if (nlevels != 4 || radius != 2) return false;
+#ifdef BHIP_EXPERIMENTS
 	{ const char* e = getenv("BHIP_FUSED_ABLATE"); if (e && (atoi(e) & 8)) return false; }
+#endif
 	const int step = sizes[1] - sizes[0];
 	if (sizes[2] - sizes[1] != step || sizes[3] - sizes[2] != step) return false;
 	return (skip == 1 && sizes[0] == 9 && step == 6) || (skip == 2 && sizes[0] == 15 && step == 12);
@@ -673,7 +675,10 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 		P.mid[m].level = midLevels[m]; P.mid[m].border = mids[m].border; P.mid[m].nbx = mids[m].nbx; P.mid[m].bitBase = mids[m].bitBase;
 		P.mid[m].sizeMid = mids[m].sizeMid; P.mid[m].sizeLower = mids[m].sizeLower;
 	}
+	P.ablate = 0;
+#ifdef BHIP_EXPERIMENTS
 	{ const char* e = getenv("BHIP_FUSED_ABLATE"); P.ablate = e ? atoi(e) : 0; }
+#endif
 	P.nexp = 0; P.expOut = nullptr; P.expW = P.expH = 0; P.expImageStride = 0; P.expLevel[0] = P.expLevel[1] = 0;
 	if (exp && exp->n > 0) {
 		P.nexp = exp->n; P.expLevel[0] = exp->level[0]; P.expLevel[1] = exp->level[1];
@@ -685,11 +690,15 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 		// algorithmic bytes of the fused octave: the integral image read once (nothing else reaches HBM but the key points)
 		ProfScope ps(ctx, skip == 1 ? "k_detect_fused_skip1" : "k_detect_fused_skipN", 4.0 * ii.width * ii.height * batch);
 		bool launched = false;
-		if (nlevels == 4 && radius == 2 && !(P.ablate & 8)) {
+		if (nlevels == 4 && radius == 2 && !BHIP_ABLATE(P, 8)) {
 			const int step = sizes[1] - sizes[0];
 			const bool arith = sizes[2] - sizes[1] == step && sizes[3] - sizes[2] == step;
+#ifdef BHIP_EXPERIMENTS
 			const char* var = getenv("BHIP_FUSED_VARIANT");   // tile-shape experiments
 			const char v = var ? var[0] : 0;
+#else
+			const char v = 0;
+#endif
 #define LAUNCH_FIXED(SK, S0, ST, ITWV, TYV)                                                                                             \
 	do {                                                                                                                               \
 		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV> G;                                                                               \

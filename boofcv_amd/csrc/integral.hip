@@ -301,15 +301,14 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 
 int bhip_launch_integral(bhip_ctx* ctx, ImgView in, ImgViewW out, int batch) {
 	if (in.width <= 0 || in.height <= 0 || batch <= 0) return BHIP_OK;
-	static int twoPass = -1;
-	if (twoPass < 0) { const char* e = getenv("BHIP_INTEGRAL_TWO_PASS"); twoPass = (e && e[0] == '1') ? 1 : 0; }   // parity cross-check / A-B timing
+	const bool twoPass = bhip_env_flag("BHIP_INTEGRAL_TWO_PASS");   // parity cross-check of the two integral plans
 	// one workgroup per image only fills the chip with a large batch; small batches keep the two streaming passes
 	const size_t lds = ((size_t)FUSED_TILE_FLOATS + FUSED_RING_FLOATS + (in.height > 1024 ? in.width : 0)) * sizeof(float);
 	if (!twoPass && batch >= FUSED_MIN_BATCH && in.data != out.data && lds <= 160 * 1024) {
-		static size_t attrLds = 0;
-		if (lds > attrLds) {
+		// the attribute is per device and this library serves one ctx per (thread, device): remember it in the ctx, not in a static
+		if (lds > ctx->integralLdsAttr) {
 			BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_integral_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			attrLds = lds;
+			ctx->integralLdsAttr = lds;
 		}
 		ProfScope ps(ctx, "k_integral_fused", 8.0 * in.width * in.height * batch);   // 4P read + 4P write
 		hipLaunchKernelGGL(k_integral_fused, dim3(batch), dim3(1024), lds, ctx->stream, in, out);

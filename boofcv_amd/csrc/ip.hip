@@ -21,6 +21,7 @@
 struct ConvParams {
 	const float* in;
 	float* out;
+	long long inImageStride, outImageStride;   // floats between the images of a batch (blockIdx.z)
 	int inStride, outStride, width, height;
 	int kw, koff;
 	int unrolled;   // first tap assigns instead of adding to 0
@@ -65,6 +66,8 @@ __device__ __forceinline__ float tapsStandard(const float* __restrict__ s, long 
 	return total;
 }
 
+// General form: one output pixel per thread, taps through L1 / L2.  Any base address, stride and width (sub-images with odd strides,
+// kernels wider than the image); the tiled kernels below take over whenever rows are 16-byte aligned.
 template <bool VERTICAL>
 __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 	const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 	const int extent = VERTICAL ? P.height : P.width;
 	const int offL = P.koff, offR = P.kw - P.koff - 1;
 	const long long step = VERTICAL ? P.inStride : 1;
-	const float* src = P.in + (long long)y * P.inStride + x;
+	const float* src = P.in + (long long)blockIdx.z * P.inImageStride + (long long)y * P.inStride + x;
 	const bool interior = pos >= offL && pos < extent - offR;
 	float result;
 	if (interior && P.mode == 3) return;
@@ -93,15 +96,154 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 		}
 		result = total / weight;
 	}
-	P.out[(long long)y * P.outStride + x] = result;
+	P.out[(long long)blockIdx.z * P.outImageStride + (long long)y * P.outStride + x] = result;
 }
 
+// ---- tiled forms: rows staged once in LDS with 16-byte loads, every tap served from LDS ----
+// One output value from `s` (taps `step` floats apart in LDS), exactly the reference's expression for the pixel's position class:
+//   interior            total = s0*k0 (unrolled widths) or 0 + s0*k0 (standard), then total += s_i*k_i in tap order
+//   border, normalised  weight += k; total += s*k over the taps inside the image, total / weight   (ConvolveNormalized_JustBorder_SB)
+// KW > 0: compile-time width (the reference's unrolled widths 3..11), KW == 0: run-time width.  Returns false when the pixel is not written.
+template <int KW>
+__device__ __forceinline__ bool convOne(const ConvParams& P, const float* s, int step, int pos, int extent, float& result) {
+	const int kw = KW > 0 ? KW : P.kw;
+	const int offL = P.koff, offR = kw - P.koff - 1;
+	const bool interior = pos >= offL && pos < extent - offR;
+	if (interior && P.mode != 2) {
+		if (P.mode == 3) return false;
+		float total;
+		if (KW > 0) {
+			float v[KW > 0 ? KW : 1];
+#pragma unroll
+			for (int i = 0; i < KW; i++) v[i] = s[i * step];
+			total = v[0] * P.k[0];
+#pragma unroll
+			for (int i = 1; i < KW; i++) total += v[i] * P.k[i];
+		} else {
+			total = P.unrolled ? s[0] * P.k[0] : 0.0f + s[0] * P.k[0];
+			int i = 1;
+			for (; i + 4 <= kw; i += 4) {
+				const float v0 = s[i * step], v1 = s[(i + 1) * step], v2 = s[(i + 2) * step], v3 = s[(i + 3) * step];
+				total += v0 * P.k[i];
+				total += v1 * P.k[i + 1];
+				total += v2 * P.k[i + 2];
+				total += v3 * P.k[i + 3];
+			}
+			for (; i < kw; i++) total += s[i * step] * P.k[i];
+		}
+		result = total;
+		return true;
+	}
+	if (P.mode == 0) return false;
+	const int k0 = max(0, offL - pos);
+	const int k1 = min(kw, extent - pos + offL);
+	float total = 0, weight = 0;
+	for (int k = k0; k < k1; k++) {
+		const float w = P.k[k];
+		weight += w;
+		total += s[k * step] * w;
+	}
+	result = total / weight;
+	return true;
+}
+
+// 16-byte load of in[gx .. gx+3] of a row of `width` floats; elements outside [0,width) read as 0 (they are never used as taps)
+__device__ __forceinline__ float4 loadRow4(const float* __restrict__ row, int gx, int width) {
+	if (gx >= 0 && gx + 3 < width) return *reinterpret_cast<const float4*>(row + gx);
+	float4 v;
+	v.x = (gx >= 0 && gx < width) ? row[gx] : 0.0f;
+	v.y = (gx + 1 >= 0 && gx + 1 < width) ? row[gx + 1] : 0.0f;
+	v.z = (gx + 2 >= 0 && gx + 2 < width) ? row[gx + 2] : 0.0f;
+	v.w = (gx + 3 >= 0 && gx + 3 < width) ? row[gx + 3] : 0.0f;
+	return v;
+}
+
+// Horizontal pass.  A block takes CT_ROWS rows x 256 columns; wave w stages and filters rows w, w+4, ...: the row segment plus the
+// kernel's reach (rounded to 16-byte chunks) goes to LDS once, then lane l produces columns l, l+64, l+128, l+192 of the segment, so
+// every LDS read and every global store of a wave touches 64 consecutive floats.
+#define CT_W 256
+#define CT_ROWS 8
+template <int KW>
+__global__ __launch_bounds__(256) void k_conv_h_tile(ConvParams P, int padL, int ldsRow) {
+	extern __shared__ float lds[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int xt0 = blockIdx.x * CT_W;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride;
+	const int nChunks = ldsRow >> 2;
+	const int y0 = blockIdx.y * CT_ROWS;
+#pragma unroll
+	for (int q = 0; q < CT_ROWS / 4; q++) {
+		const int y = y0 + wave + 4 * q;
+		if (y >= P.height) break;
+		const float* src = img + (long long)y * P.inStride;
+		float* row = lds + (wave + 4 * q) * ldsRow;
+		for (int c = lane; c < nChunks; c += 64) *reinterpret_cast<float4*>(row + 4 * c) = loadRow4(src, xt0 - padL + 4 * c, P.width);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < CT_ROWS / 4; q++) {
+		const int y = y0 + wave + 4 * q;
+		if (y >= P.height) break;
+		const float* row = lds + (wave + 4 * q) * ldsRow + padL - P.koff;
+		float* dst = outImg + (long long)y * P.outStride;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const int xl = lane + 64 * j, x = xt0 + xl;
+			float r;
+			if (x < P.width && convOne<KW>(P, row + xl, 1, x, P.width, r)) dst[x] = r;
+		}
+	}
+}
+
+// Vertical pass.  A block takes CV_ROWS output rows x 256 columns: the CV_ROWS + kw - 1 input rows are staged in LDS (one row per wave
+// instruction, 16 bytes per lane), then wave w filters rows w, w+4, ...; lane l owns columns 4l .. 4l+3, so taps are ds_read_b128
+// and results leave as 16-byte stores.
+#define CV_ROWS 32
+template <int KW>
+__global__ __launch_bounds__(256) void k_conv_v_tile(ConvParams P) {
+	extern __shared__ float lds[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * CT_W + 4 * lane;
+	const int y0 = blockIdx.y * CV_ROWS;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride;
+	const int kw = KW > 0 ? KW : P.kw;
+	const int nStage = min(CV_ROWS, P.height - y0) + kw - 1;
+	const int yTop = y0 - P.koff;
+	if (x < P.width) {
+		for (int i = wave; i < nStage; i += 4) {
+			const int yy = yTop + i;
+			if (yy >= 0 && yy < P.height) *reinterpret_cast<float4*>(lds + i * CT_W + 4 * lane) = loadRow4(img + (long long)yy * P.inStride, x, P.width);
+		}
+	}
+	__syncthreads();
+	if (x >= P.width) return;
+	for (int q = wave; q < CV_ROWS; q += 4) {
+		const int y = y0 + q;
+		if (y >= P.height) break;
+		const float* s = lds + q * CT_W + 4 * lane;
+		float r[4];
+		bool wr = true;
+#pragma unroll
+		for (int j = 0; j < 4; j++) wr = convOne<KW>(P, s + j, CT_W, y, P.height, r[j]);   // same position class for the four columns
+		if (!wr) continue;
+		float* dst = outImg + (long long)y * P.outStride + x;
+		if (x + 3 < P.width) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+		else
+			for (int j = 0; j < 4 && x + j < P.width; j++) dst[j] = r[j];
+	}
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
-					 int height, float* out, int outStride) {
+					 int height, float* out, int outStride, int batch, long long inImageStride, long long outImageStride) {
 	if (kw <= 0 || kw > BHIP_MAX_TAPS || koff < 0 || koff >= kw) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "kernel width not supported");
-	if (width <= 0 || height <= 0) return BHIP_OK;
+	if (width <= 0 || height <= 0 || batch <= 0) return BHIP_OK;
 	ConvParams P;
 	P.in = in; P.out = out; P.inStride = inStride; P.outStride = outStride; P.width = width; P.height = height; P.kw = kw; P.koff = koff;
+	P.inImageStride = inImageStride; P.outImageStride = outImageStride;
 	for (int i = 0; i < kw; i++) P.k[i] = kernel[i];
 	P.unrolled = (koff == kw / 2 && kw % 2 == 1 && (kw == 3 || kw == 5 || kw == 7 || kw == 9 || kw == 11)) ? 1 : 0;
 	P.mode = 0;
@@ -123,10 +265,44 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 			}
 		}
 	}
-	dim3 grid((width + 255) / 256, height);
-	ProfScope prof(ctx, vertical ? "k_conv_v" : "k_conv_h", 8.0 * width * height);
-	if (vertical) hipLaunchKernelGGL(k_conv<true>, grid, dim3(256), 0, ctx->stream, P);
-	else hipLaunchKernelGGL(k_conv<false>, grid, dim3(256), 0, ctx->stream, P);
+	ProfScope prof(ctx, vertical ? "k_conv_v" : "k_conv_h", 8.0 * width * height * batch);
+	// tiled forms need 16-byte aligned rows on both sides; the naive form (kernel wider than the image) stays on the general kernel
+	const bool tiled = P.mode != 2 && aligned16(in) && aligned16(out) && inStride % 4 == 0 && outStride % 4 == 0 && inImageStride % 4 == 0 &&
+					   outImageStride % 4 == 0 && kw <= 97;
+	if (!tiled) {
+		dim3 grid((width + 255) / 256, height, batch);
+		if (vertical) hipLaunchKernelGGL(k_conv<true>, grid, dim3(256), 0, ctx->stream, P);
+		else hipLaunchKernelGGL(k_conv<false>, grid, dim3(256), 0, ctx->stream, P);
+	} else if (vertical) {
+		dim3 grid((width + CT_W - 1) / CT_W, (height + CV_ROWS - 1) / CV_ROWS, batch);
+		const size_t ldsBytes = (size_t)(CV_ROWS + kw - 1) * CT_W * 4;
+#define LAUNCH_V(KWT)                                                                                                   \
+	do {                                                                                                                \
+		if (ldsBytes > 65536) BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_conv_v_tile<KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
+		hipLaunchKernelGGL(k_conv_v_tile<KWT>, grid, dim3(256), ldsBytes, ctx->stream, P);                              \
+	} while (0)
+		if (P.unrolled && kw == 3) LAUNCH_V(3);
+		else if (P.unrolled && kw == 5) LAUNCH_V(5);
+		else if (P.unrolled && kw == 7) LAUNCH_V(7);
+		else if (P.unrolled && kw == 9) LAUNCH_V(9);
+		else if (P.unrolled && kw == 11) LAUNCH_V(11);
+		else LAUNCH_V(0);
+#undef LAUNCH_V
+	} else {
+		const int offR = kw - koff - 1;
+		const int padL = (koff + 3) & ~3, padR = (offR + 3) & ~3;
+		const int ldsRow = CT_W + padL + padR;
+		dim3 grid((width + CT_W - 1) / CT_W, (height + CT_ROWS - 1) / CT_ROWS, batch);
+		const size_t ldsBytes = (size_t)CT_ROWS * ldsRow * 4;
+#define LAUNCH_H(KWT) hipLaunchKernelGGL(k_conv_h_tile<KWT>, grid, dim3(256), ldsBytes, ctx->stream, P, padL, ldsRow)
+		if (P.unrolled && kw == 3) LAUNCH_H(3);
+		else if (P.unrolled && kw == 5) LAUNCH_H(5);
+		else if (P.unrolled && kw == 7) LAUNCH_H(7);
+		else if (P.unrolled && kw == 9) LAUNCH_H(9);
+		else if (P.unrolled && kw == 11) LAUNCH_H(11);
+		else LAUNCH_H(0);
+#undef LAUNCH_H
+	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
@@ -262,93 +438,191 @@ struct GradParams {
 	const float* in;
 	float* dx;
 	float* dy;
+	long long inImageStride, outImageStride;   // floats between the images of a batch
 	int inStride, outStride, width, height;
 	int border;  // 0: frame untouched, 1: ImageBorderValue(0)
 };
 
-__device__ __forceinline__ float at0(const GradParams& P, int x, int y) {
-	return (x >= 0 && x < P.width && y >= 0 && y < P.height) ? P.in[(long long)y * P.inStride + x] : 0.0f;
+__device__ __forceinline__ float at0(const GradParams& P, const float* img, int x, int y) {
+	return (x >= 0 && x < P.width && y >= 0 && y < P.height) ? img[(long long)y * P.inStride + x] : 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_sobel(GradParams P) {
-	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-	if (x >= P.width) return;
-	const long long o = (long long)y * P.outStride + x;
-	if (x >= 1 && x < P.width - 1 && y >= 1 && y < P.height - 1) {
-		const float* c = P.in + (long long)y * P.inStride + x;
-		const int s = P.inStride;
-		const float a11 = c[-s - 1], a12 = c[-s], a13 = c[-s + 1];
-		const float a21 = c[-1], a23 = c[1];
-		const float a31 = c[s - 1], a32 = c[s], a33 = c[s + 1];
-		const float v = (a33 - a11) * 0.25f;
-		const float w = (a31 - a13) * 0.25f;
-		P.dy[o] = (a32 - a12) * 0.5f + v + w;
-		P.dx[o] = (a23 - a21) * 0.5f + v - w;
-	} else if (P.border) {
-		// generic border convolution with GradientSobel.kernelDerivX/Y_F32: total = 0; total += get(x+j,y+i)*k in row-major kernel order
+// One pixel of GradientSobel / GradientThree from its 3x3 neighbourhood a[row][col] (0 outside the image), reference expressions:
+//   Sobel interior   GradientSobel_UnrolledOuter.process_F32_sub; frame with a border = generic border convolution with kernelDerivX/Y_F32
+//                    (total = 0; total += get(x+j,y+i)*k in row-major kernel order)
+//   three-tap        GradientThree_Standard.process inside; with a border the first/last column (row) of derivX (derivY) takes the generic
+//                    form, rows {0,1,H-2,H-1} (columns for derivY) the unrolled 3-tap form
+// Returns false when the pixel is left untouched (frame pixel, no border policy).
+template <int KIND>
+__device__ __forceinline__ bool gradOne(const float a[3][3], int x, int y, int W, int H, int border, float& dx, float& dy) {
+	const bool interior = x >= 1 && x < W - 1 && y >= 1 && y < H - 1;
+	if (KIND == 0) {
+		if (interior) {
+			const float v = (a[2][2] - a[0][0]) * 0.25f;
+			const float w = (a[2][0] - a[0][2]) * 0.25f;
+			dy = (a[2][1] - a[0][1]) * 0.5f + v + w;
+			dx = (a[1][2] - a[1][0]) * 0.5f + v - w;
+			return true;
+		}
+		if (!border) return false;
 		const float kx[9] = {-0.25f, 0, 0.25f, -0.5f, 0, 0.5f, -0.25f, 0, 0.25f};
 		const float ky[9] = {-0.25f, -0.5f, -0.25f, 0, 0, 0, 0.25f, 0.5f, 0.25f};
 		float tx = 0, ty = 0;
-		int ik = 0;
-		for (int i = -1; i <= 1; i++)
-			for (int j = -1; j <= 1; j++, ik++) {
-				const float p = at0(P, x + j, y + i);
-				tx += p * kx[ik];
-				ty += p * ky[ik];
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+#pragma unroll
+			for (int j = 0; j < 3; j++) {
+				tx += a[i][j] * kx[i * 3 + j];
+				ty += a[i][j] * ky[i * 3 + j];
 			}
-		P.dx[o] = tx;
-		P.dy[o] = ty;
+		dx = tx; dy = ty;
+		return true;
 	}
-}
-
-__global__ __launch_bounds__(256) void k_three(GradParams P) {
-	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-	if (x >= P.width) return;
-	const long long o = (long long)y * P.outStride + x;
-	const int W = P.width, H = P.height;
-	const float* c = P.in + (long long)y * P.inStride + x;
-	const int s = P.inStride;
-	const bool interior = x >= 1 && x < W - 1 && y >= 1 && y < H - 1;
-	if (!P.border) {
-		if (interior) {
-			P.dx[o] = (c[1] - c[-1]) * 0.5f;
-			P.dy[o] = (c[s] - c[-s]) * 0.5f;
-		}
-		return;
+	if (!border) {
+		if (!interior) return false;
+		dx = (a[1][2] - a[1][0]) * 0.5f;
+		dy = (a[2][1] - a[0][1]) * 0.5f;
+		return true;
 	}
 	const float k0 = -0.5f, k1 = 0.0f, k2 = 0.5f;
-	// derivX: generic border form on the first/last column, unrolled 3-tap form on rows {0,1,H-2,H-1}, else the interior expression
-	float dx, dy;
 	if (x == 0 || x == W - 1) {
 		float t = 0;
-		t += at0(P, x - 1, y) * k0; t += at0(P, x, y) * k1; t += at0(P, x + 1, y) * k2;
+		t += a[1][0] * k0; t += a[1][1] * k1; t += a[1][2] * k2;
 		dx = t;
 	} else if (y <= 1 || y >= H - 2) {
-		float t = c[-1] * k0; t += c[0] * k1; t += c[1] * k2;
+		float t = a[1][0] * k0; t += a[1][1] * k1; t += a[1][2] * k2;
 		dx = t;
 	} else {
-		dx = (c[1] - c[-1]) * 0.5f;
+		dx = (a[1][2] - a[1][0]) * 0.5f;
 	}
 	if (y == 0 || y == H - 1) {
 		float t = 0;
-		t += at0(P, x, y - 1) * k0; t += at0(P, x, y) * k1; t += at0(P, x, y + 1) * k2;
+		t += a[0][1] * k0; t += a[1][1] * k1; t += a[2][1] * k2;
 		dy = t;
 	} else if (x <= 1 || x >= W - 2) {
-		float t = c[-s] * k0; t += c[0] * k1; t += c[s] * k2;
+		float t = a[0][1] * k0; t += a[1][1] * k1; t += a[2][1] * k2;
 		dy = t;
 	} else {
-		dy = (c[s] - c[-s]) * 0.5f;
+		dy = (a[2][1] - a[0][1]) * 0.5f;
 	}
+	return true;
+}
+
+// General form: one pixel per thread, any alignment
+template <int KIND>
+__global__ __launch_bounds__(256) void k_grad(GradParams P) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= P.width) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float a[3][3];
+#pragma unroll
+	for (int i = 0; i < 3; i++)
+#pragma unroll
+		for (int j = 0; j < 3; j++) a[i][j] = at0(P, img, x + j - 1, y + i - 1);
+	float dx, dy;
+	if (!gradOne<KIND>(a, x, y, P.width, P.height, P.border, dx, dy)) return;
+	const long long o = (long long)blockIdx.z * P.outImageStride + (long long)y * P.outStride + x;
 	P.dx[o] = dx;
 	P.dy[o] = dy;
 }
 
-int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border) {
-	if (width <= 0 || height <= 0) return BHIP_OK;
-	GradParams P{in, dx, dy, inStride, outStride, width, height, border};
-	dim3 grid((width + 255) / 256, height);
-	if (kind == 0) hipLaunchKernelGGL(k_sobel, grid, dim3(256), 0, ctx->stream, P);
-	else hipLaunchKernelGGL(k_three, grid, dim3(256), 0, ctx->stream, P);
+// Streaming form: a wave walks GR_ROWS rows of a 256-column strip; lane l owns columns 4l .. 4l+3 and keeps a three-row window in
+// registers, so every input row is loaded once per strip (16 bytes per lane); the two columns beside a lane's four come from the
+// neighbouring lanes, the strip's outermost two from single loads.  Outputs leave as 16-byte stores.  HBM: 4P read + 8P written.
+#define GR_ROWS 16
+struct GradRow { float v[6]; };   // columns x-1 .. x+4 of one row (0 outside the image)
+__device__ __forceinline__ GradRow gradLoadRow(const GradParams& P, const float* img, int x, int y, int lane) {
+	GradRow r;
+	if (y < 0 || y >= P.height) {
+#pragma unroll
+		for (int i = 0; i < 6; i++) r.v[i] = 0.0f;
+		return r;
+	}
+	const float* row = img + (long long)y * P.inStride;
+	const float4 c = x < P.width ? loadRow4(row, x, P.width) : make_float4(0, 0, 0, 0);
+	float left = __shfl_up(c.w, 1, 64), right = __shfl_down(c.x, 1, 64);
+	if (lane == 0) left = (x - 1 >= 0 && x - 1 < P.width) ? row[x - 1] : 0.0f;
+	if (lane == 63) right = (x + 4 < P.width) ? row[x + 4] : 0.0f;
+	r.v[0] = left; r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w; r.v[5] = right;
+	return r;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void k_grad_stream(GradParams P) {
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;
+	const int y0 = (blockIdx.y * 4 + wave) * GR_ROWS;
+	if (y0 >= P.height) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* dxImg = P.dx + (long long)blockIdx.z * P.outImageStride;
+	float* dyImg = P.dy + (long long)blockIdx.z * P.outImageStride;
+	GradRow r0 = gradLoadRow(P, img, x, y0 - 1, lane), r1 = gradLoadRow(P, img, x, y0, lane);
+	const int yEnd = min(y0 + GR_ROWS, P.height);
+	for (int y = y0; y < yEnd; y++) {
+		const GradRow r2 = gradLoadRow(P, img, x, y + 1, lane);
+		if (x < P.width) {
+			float dx[4], dy[4];
+			bool wr[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const float a[3][3] = {{r0.v[j], r0.v[j + 1], r0.v[j + 2]}, {r1.v[j], r1.v[j + 1], r1.v[j + 2]}, {r2.v[j], r2.v[j + 1], r2.v[j + 2]}};
+				wr[j] = gradOne<KIND>(a, x + j, y, P.width, P.height, P.border, dx[j], dy[j]);
+			}
+			const long long o = (long long)y * P.outStride + x;
+			if (x + 3 < P.width && wr[0] && wr[1] && wr[2] && wr[3]) {
+				*reinterpret_cast<float4*>(dxImg + o) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+				*reinterpret_cast<float4*>(dyImg + o) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					if (x + j < P.width && wr[j]) { dxImg[o + j] = dx[j]; dyImg[o + j] = dy[j]; }
+			}
+		}
+		r0 = r1; r1 = r2;
+	}
+}
+
+int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride, int width, int height, float* dx, float* dy, int outStride, int border,
+						 int batch, long long inImageStride, long long outImageStride) {
+	if (width <= 0 || height <= 0 || batch <= 0) return BHIP_OK;
+	GradParams P{in, dx, dy, inImageStride, outImageStride, inStride, outStride, width, height, border};
+	ProfScope prof(ctx, kind == 0 ? "k_sobel" : "k_three", 12.0 * width * height * batch);
+	const bool stream = aligned16(in) && aligned16(dx) && aligned16(dy) && inStride % 4 == 0 && outStride % 4 == 0 && inImageStride % 4 == 0 &&
+						outImageStride % 4 == 0;
+	if (stream) {
+		dim3 grid((width + 255) / 256, (height + 4 * GR_ROWS - 1) / (4 * GR_ROWS), batch);
+		if (kind == 0) hipLaunchKernelGGL(k_grad_stream<0>, grid, dim3(256), 0, ctx->stream, P);
+		else hipLaunchKernelGGL(k_grad_stream<1>, grid, dim3(256), 0, ctx->stream, P);
+	} else {
+		dim3 grid((width + 255) / 256, height, batch);
+		if (kind == 0) hipLaunchKernelGGL(k_grad<0>, grid, dim3(256), 0, ctx->stream, P);
+		else hipLaunchKernelGGL(k_grad<1>, grid, dim3(256), 0, ctx->stream, P);
+	}
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// GradientToEdgeFeatures.intensityE / intensityAbs (F:alg/feature/detect/edge/impl/ImplGradientToEdgeFeatures.java:40-85) and the squared
+// magnitude dx*dx + dy*dy (no reference function of its own: the |grad|^2 of BASELINE config 5; same products and sum as intensityE,
+// without the square root).  Element-wise, 8P read + 4P written.
+__global__ __launch_bounds__(256) void k_grad_intensity(const float* __restrict__ dx, const float* __restrict__ dy, long long dImageStride, int dStride,
+														 float* __restrict__ out, long long oImageStride, int oStride, int width, int height, int kind) {
+	const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+	if (x >= width) return;
+	const long long i = (long long)blockIdx.z * dImageStride + (long long)y * dStride + x;
+	const float a = dx[i], b = dy[i];
+	float r;
+	if (kind == 0) r = sqrtf(a * a + b * b);           // (float)Math.sqrt((double)f): correctly rounded, as sqrtf
+	else if (kind == 1) r = fabsf(a) + fabsf(b);
+	else r = a * a + b * b;
+	out[(long long)blockIdx.z * oImageStride + (long long)y * oStride + x] = r;
+}
+int bhip_launch_grad_intensity(bhip_ctx* ctx, int kind, const float* dx, const float* dy, long long dImageStride, int dStride, float* out,
+							   long long oImageStride, int oStride, int width, int height, int batch) {
+	if (kind < 0 || kind > 2) return bhip_fail(ctx, BHIP_ERR_INVALID, "unknown gradient intensity");
+	if (width <= 0 || height <= 0 || batch <= 0) return BHIP_OK;
+	ProfScope prof(ctx, "k_grad_intensity", 12.0 * width * height * batch);
+	hipLaunchKernelGGL(k_grad_intensity, dim3((width + 255) / 256, height, batch), dim3(256), 0, ctx->stream, dx, dy, dImageStride, dStride, out, oImageStride,
+					   oStride, width, height, kind);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
@@ -356,30 +630,35 @@ int bhip_launch_gradient(bhip_ctx* ctx, int kind, const float* in, int inStride,
 // ---------------- BRIEF ----------------
 struct BriefParams {
 	const float* img;
+	long long imageStride;    // elements between the images of a batch
 	int stride, width, height, radius, numPoints, words, n;
 	const int* samplePoints;  // [numPoints][2]
 	const int* compare;       // [numPoints][2]
 	const double* xy;         // [n][2]
 	int* out;                 // [n][words]
+	const int* start;         // batched: points of image b are [start[b], start[b+1]); nullptr: one image, n points
 };
 
 // one thread = one 32-pair word of one key point.  PIX = float (ImplDescribeBinaryCompare_F32: a pair outside the image is skipped
 // without shifting the word) or unsigned char (ImplDescribeBinaryCompare_U8.java:73-101: the word is shifted for EVERY pair)
 template <class PIX>
 __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
+	const int first = P.start ? P.start[blockIdx.y] : 0;
+	const int count = P.start ? P.start[blockIdx.y + 1] - first : P.n;
 	const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= (long long)P.n * P.words) return;
-	const int p = (int)(t / P.words), word = (int)(t - (long long)p * P.words);
+	if (t >= (long long)count * P.words) return;
+	const int pl = (int)(t / P.words), word = (int)(t - (long long)pl * P.words);
+	const int p = first + pl;
 	const int c_x = (int)P.xy[2 * p], c_y = (int)P.xy[2 * p + 1];
 	const bool inside = !(c_x - P.radius < 0 || c_x + P.radius >= P.width || c_y - P.radius < 0 || c_y + P.radius >= P.height);
 	const int i0 = word * 32, i1 = min(P.numPoints, i0 + 32);
+	const PIX* img = (const PIX*)P.img + (long long)blockIdx.y * P.imageStride;
 	unsigned int desc = 0;
 	for (int j = i0; j < i1; j++) {
 		const int ia = P.compare[2 * j], ib = P.compare[2 * j + 1];
 		const int ax = P.samplePoints[2 * ia] + c_x, ay = P.samplePoints[2 * ia + 1] + c_y;
 		const int bx = P.samplePoints[2 * ib] + c_x, by = P.samplePoints[2 * ib + 1] + c_y;
 		const bool ok = inside || (ax >= 0 && ax < P.width && ay >= 0 && ay < P.height && bx >= 0 && bx < P.width && by >= 0 && by < P.height);
-		const PIX* img = (const PIX*)P.img;
 		if (sizeof(PIX) == 1) {
 			desc = desc * 2u;
 			if (ok && img[(long long)ay * P.stride + ax] < img[(long long)by * P.stride + bx]) desc += 1u;
@@ -389,16 +668,20 @@ __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 			desc = desc * 2u + (va < vb ? 1u : 0u);
 		}
 	}
-	P.out[t] = (int)desc;
+	P.out[(long long)p * P.words + word] = (int)desc;
 }
 
+// start == nullptr: n points on one image.  Otherwise `batch` images and device prefix `start` (batch+1); maxCount = largest per-image count.
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
-					  const int* compare, const double* xy, int n, int* out, bool u8) {
+					  const int* compare, const double* xy, int n, int* out, bool u8, int batch, long long imageStride, const int* start, int maxCount) {
 	if (n <= 0) return BHIP_OK;
-	BriefParams P{img, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out};
-	const long long total = (long long)n * P.words;
-	if (u8) hipLaunchKernelGGL(k_brief<unsigned char>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, P);
-	else hipLaunchKernelGGL(k_brief<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, P);
+	BriefParams P{img, imageStride, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out, start};
+	const long long total = (long long)(start ? maxCount : n) * P.words;
+	if (total <= 0) return BHIP_OK;
+	dim3 grid((unsigned)((total + 255) / 256), start ? batch : 1);
+	ProfScope prof(ctx, "k_brief");
+	if (u8) hipLaunchKernelGGL(k_brief<unsigned char>, grid, dim3(256), 0, ctx->stream, P);
+	else hipLaunchKernelGGL(k_brief<float>, grid, dim3(256), 0, ctx->stream, P);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
@@ -444,6 +727,7 @@ int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long band
 // latency chain over W per row (each lane streams its own row through L1); the vertical pass is coalesced and HBM bound (12P read, 4P write).
 struct CornerParams {
 	const float* dx; const float* dy;
+	long long dImageStride, hImageStride, iImageStride;   // floats between the images of a batch (blockIdx.y)
 	int dStride, width, height, radius;
 	float* hXX; float* hXY; float* hYY;   // dense width x height planes
 	float* intensity; int iStride;
@@ -454,9 +738,10 @@ __global__ __launch_bounds__(64) void k_corner_rows(CornerParams P) {
 	const int row = blockIdx.x * blockDim.x + threadIdx.x;
 	if (row >= P.height) return;
 	const int W = P.width, r = P.radius, ww = 2 * r + 1;
-	const float* __restrict__ X = P.dx + (long long)row * P.dStride;
-	const float* __restrict__ Y = P.dy + (long long)row * P.dStride;
-	float* oXX = P.hXX + (long long)row * W; float* oXY = P.hXY + (long long)row * W; float* oYY = P.hYY + (long long)row * W;
+	const float* __restrict__ X = P.dx + (long long)blockIdx.y * P.dImageStride + (long long)row * P.dStride;
+	const float* __restrict__ Y = P.dy + (long long)blockIdx.y * P.dImageStride + (long long)row * P.dStride;
+	const long long ho = (long long)blockIdx.y * P.hImageStride + (long long)row * W;
+	float* oXX = P.hXX + ho; float* oXY = P.hXY + ho; float* oYY = P.hYY + ho;
 	float tXX = 0, tXY = 0, tYY = 0;
 	for (int i = 0; i < ww; i++) {
 		const float dx = X[i], dy = Y[i];
@@ -502,13 +787,16 @@ __global__ __launch_bounds__(256) void k_corner_cols(CornerParams P) {
 	const int W = P.width, H = P.height, r = P.radius, kw = 2 * r + 1;
 	const int x = r + blockIdx.x * blockDim.x + threadIdx.x;
 	if (x >= W - r) return;
-	const float* __restrict__ hXX = P.hXX; const float* __restrict__ hXY = P.hXY; const float* __restrict__ hYY = P.hYY;
+	const float* __restrict__ hXX = P.hXX + (long long)blockIdx.y * P.hImageStride;
+	const float* __restrict__ hXY = P.hXY + (long long)blockIdx.y * P.hImageStride;
+	const float* __restrict__ hYY = P.hYY + (long long)blockIdx.y * P.hImageStride;
+	float* __restrict__ inten = P.intensity + (long long)blockIdx.y * P.iImageStride;
 	float tXX = 0, tXY = 0, tYY = 0;
 	for (int k = 0; k < kw; k++) {
 		const long long s = (long long)k * W + x;
 		tXX += hXX[s]; tXY += hXY[s]; tYY += hYY[s];
 	}
-	P.intensity[(long long)r * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
+	inten[(long long)r * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
 	int y = r + 1;
 	for (; y + 8 <= H - r; y += 8) {
 		float a[3][8], b[3][8];
@@ -523,7 +811,7 @@ __global__ __launch_bounds__(256) void k_corner_cols(CornerParams P) {
 			tXX = tXX - a[0][k]; tXX += b[0][k];
 			tXY = tXY - a[1][k]; tXY += b[1][k];
 			tYY = tYY - a[2][k]; tYY += b[2][k];
-			P.intensity[(long long)(y + k) * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
+			inten[(long long)(y + k) * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
 		}
 	}
 	for (; y < H - r; y++) {
@@ -531,23 +819,26 @@ __global__ __launch_bounds__(256) void k_corner_cols(CornerParams P) {
 		tXX = tXX - hXX[out]; tXX += hXX[in];
 		tXY = tXY - hXY[out]; tXY += hXY[in];
 		tYY = tYY - hYY[out]; tYY += hYY[in];
-		P.intensity[(long long)y * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
+		inten[(long long)y * P.iStride + x] = cornerScore(P.kind, P.kappa, tXX, tXY, tYY);
 	}
 }
 
-// intensity (dense, iStride == width here) must be zero along its border of `radius` pixels: the caller clears the whole image first
+// intensity must be zero along its border of `radius` pixels: the caller clears the whole image first.  hXX/hXY/hYY: dense width x height
+// planes per image, hImageStride floats apart.
 int bhip_launch_corner_intensity(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dx, const float* dy, int dStride, int width, int height,
-								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride) {
+								 float* hXX, float* hXY, float* hYY, float* intensity, int iStride, int batch, long long dImageStride, long long hImageStride,
+								 long long iImageStride) {
 	if (kind != 0 && kind != 1) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "corner score not supported");
 	if (radius < 0 || 2 * radius + 1 > width || 2 * radius + 1 > height) return bhip_fail(ctx, BHIP_ERR_INVALID, "window larger than the image");
-	CornerParams P{dx, dy, dStride, width, height, radius, hXX, hXY, hYY, intensity, iStride, kind, kappa};
+	if (batch <= 0) return BHIP_OK;
+	CornerParams P{dx, dy, dImageStride, hImageStride, iImageStride, dStride, width, height, radius, hXX, hXY, hYY, intensity, iStride, kind, kappa};
 	{
-		ProfScope prof(ctx, "k_corner_rows", 4.0 * width * height * 5);
-		hipLaunchKernelGGL(k_corner_rows, dim3((height + 63) / 64), dim3(64), 0, ctx->stream, P);
+		ProfScope prof(ctx, "k_corner_rows", 4.0 * width * height * 5 * batch);
+		hipLaunchKernelGGL(k_corner_rows, dim3((height + 63) / 64, batch), dim3(64), 0, ctx->stream, P);
 	}
 	{
-		ProfScope prof(ctx, "k_corner_cols", 4.0 * width * height * 4);
-		hipLaunchKernelGGL(k_corner_cols, dim3((width - 2 * radius + 255) / 256), dim3(256), 0, ctx->stream, P);
+		ProfScope prof(ctx, "k_corner_cols", 4.0 * width * height * 4 * batch);
+		hipLaunchKernelGGL(k_corner_cols, dim3((width - 2 * radius + 255) / 256, batch), dim3(256), 0, ctx->stream, P);
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
@@ -664,6 +955,7 @@ int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, 
 	{
 		ConvParams P;
 		P.in = in; P.out = out; P.inStride = width; P.outStride = width; P.width = width; P.height = height; P.kw = kw; P.koff = radius;
+		P.inImageStride = 0; P.outImageStride = 0;
 		for (int i = 0; i < kw; i++) P.k[i] = ker[i];
 		P.unrolled = 0; P.mode = 3;
 		dim3 grid((width + 255) / 256, height);

@@ -10,8 +10,11 @@ static hipEvent_t takeEvent(bhip_ctx* ctx) {
 	return e;
 }
 
+// records kept between two bhip_profile_reset calls (a caller that never resets stops collecting instead of growing without bound)
+#define BHIP_PROF_MAX_RECORDS (1 << 18)
+
 ProfScope::ProfScope(bhip_ctx* c, const char* tag, double algBytes, double algFlops) : ctx(c) {
-	if (!ctx || !ctx->profiling) return;
+	if (!ctx || !ctx->profiling || ctx->profRecords.size() >= BHIP_PROF_MAX_RECORDS) return;
 	ProfRecord r;
 	r.tag = tag; r.algBytes = algBytes; r.algFlops = algFlops;
 	r.start = takeEvent(ctx);
@@ -22,6 +25,14 @@ ProfScope::ProfScope(bhip_ctx* c, const char* tag, double algBytes, double algFl
 }
 ProfScope::~ProfScope() {
 	if (idx >= 0) (void)hipEventRecord(ctx->profRecords[idx].stop, ctx->stream);
+}
+
+// ctx teardown: every event ever created for this ctx sits in profRecords or in the pool
+void bhip_profile_release(bhip_ctx* ctx) {
+	for (auto& r : ctx->profRecords) { if (r.start) (void)hipEventDestroy(r.start); if (r.stop) (void)hipEventDestroy(r.stop); }
+	ctx->profRecords.clear();
+	for (hipEvent_t e : ctx->eventPool) if (e) (void)hipEventDestroy(e);
+	ctx->eventPool.clear();
 }
 
 struct ProfAgg { double ms = 0, bytes = 0, flops = 0; long long launches = 0; };

@@ -287,6 +287,46 @@ int bhip_brief_u8(bhip_ctx* ctx, const uint8_t* img, int start, int stride, int 
 int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int width, int height, int radius, int numPoints,
 				   const int32_t* samplePoints, const int32_t* compare, const double* xy, int n, int32_t* out);
 
+/* ---- device-resident, batched forms of the boofcv-ip front end (BASELINE config 5: pyramid -> gradient -> non-max -> SURF on a 4K stream that
+ *      never leaves HBM).  Image b of a batch starts imageStride floats after image 0, rows are `stride` floats apart; calls are asynchronous on
+ *      the ctx stream.  Same kernels and arithmetic as the host-buffer entry points above (each cites the same reference function). ---- */
+/* ConvolveImageNoBorder.horizontal / vertical (I:alg/filter/convolve/ConvolveImageNoBorder.java:53-77): frame of dev_out untouched */
+int bhip_conv_h_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* dev_in, long long inImageStride, int inStride,
+						int width, int height, int batch, float* dev_out, long long outImageStride, int outStride);
+int bhip_conv_v_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* dev_in, long long inImageStride, int inStride,
+						int width, int height, int batch, float* dev_out, long long outImageStride, int outStride);
+/* ConvolveImageNormalized.horizontal / vertical (I:alg/filter/convolve/ConvolveImageNormalized.java:48-93) */
+int bhip_conv_norm_h_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* dev_in, long long inImageStride, int inStride,
+							 int width, int height, int batch, float* dev_out, long long outImageStride, int outStride);
+int bhip_conv_norm_v_dev_f32(bhip_ctx* ctx, const float* kernel, int kernelWidth, int kernelOffset, const float* dev_in, long long inImageStride, int inStride,
+							 int width, int height, int batch, float* dev_out, long long outImageStride, int outStride);
+/* BlurImageOps.gaussian(GrayF32, out, sigma, radius, storage) (I:alg/filter/blur/BlurImageOps.java:406-425); `storage` is library scratch */
+int bhip_gaussian_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, double sigma, int radius,
+						  float* dev_out, long long outImageStride, int outStride);
+/* GradientSobel.process (I:alg/filter/derivative/GradientSobel.java:158-173) / GradientThree.process -> GradientThree_Standard
+ * (I:alg/filter/derivative/impl/GradientThree_Standard.java:40-62); dx and dy share outImageStride / outStride; border as in bhip_sobel_f32 */
+int bhip_sobel_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, float* dev_dx, float* dev_dy,
+					   long long outImageStride, int outStride, int border);
+int bhip_three_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageStride, int inStride, int width, int height, int batch, float* dev_dx, float* dev_dy,
+					   long long outImageStride, int outStride, int border);
+/* Gradient magnitude images: kind 0 = GradientToEdgeFeatures.intensityE, (float)Math.sqrt(dx*dx + dy*dy); kind 1 = intensityAbs, |dx| + |dy|
+ * (F:alg/feature/detect/edge/GradientToEdgeFeatures.java:61-95 -> impl/ImplGradientToEdgeFeatures.java:40-85); kind 2 = dx*dx + dy*dy, the
+ * |grad|^2 image BASELINE config 5 runs the non-max suppression on (the products and the sum of intensityE without the root) */
+int bhip_gradient_intensity_dev_f32(bhip_ctx* ctx, int kind, const float* dev_dx, const float* dev_dy, long long dImageStride, int dStride, int width,
+									int height, int batch, float* dev_out, long long outImageStride, int outStride);
+/* NonMaxBlock.process, strict rule (F:alg/feature/detect/extract/NonMaxBlock.java:69-94; NonMaxBlockSearchStrict.java:56-79,196-221) on every image of
+ * a batch: image b's maxima go to dev_xy[b*cap ...] as (x,y) int16 pairs in block-raster order, their number to dev_n[b] (it may exceed cap;
+ * only the first cap pairs are written) */
+int bhip_nonmax_block_dev_f32(bhip_ctx* ctx, const float* dev_intensity, long long imageStride, int stride, int width, int height, int batch, int radius,
+							  float threshold, int border, int16_t* dev_xy, int cap, int* dev_n);
+/* GradientCornerIntensity.process (see bhip_corner_intensity_f32) on a batch; derivX / derivY share dImageStride / dStride */
+int bhip_corner_intensity_dev_f32(bhip_ctx* ctx, int kind, int radius, float kappa, const float* dev_dx, const float* dev_dy, long long dImageStride,
+								  int dStride, int width, int height, int batch, float* dev_intensity, long long iImageStride, int iStride);
+/* DescribePointBrief.process (see bhip_brief_f32) for the points of a batch: image b owns points [start[b], start[b+1]) of dev_xy ((x,y) doubles;
+ * `start` is a host array of batch+1 entries); point p's words go to dev_out[p * ceil(numPoints/32) ...] */
+int bhip_brief_dev_f32(bhip_ctx* ctx, const float* dev_img, long long imageStride, int stride, int width, int height, int batch, int radius, int numPoints,
+					   const int32_t* samplePoints, const int32_t* compare, const double* dev_xy, const int* start, int32_t* dev_out);
+
 #ifdef __cplusplus
 }
 #endif

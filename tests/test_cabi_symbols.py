@@ -61,3 +61,13 @@ def test_config_defaults_match_reference():
     assert (o.objectRadiusToScale, o.samplePeriod, o.radius, o.weightSigma, o.sampleWidth) == (0.5, 0.65, 8, -1.0, 6) and abs(o.windowSize - 3.141592653589793 / 3) < 1e-15
     L.bhip_ori_cfg_default(o, 0)
     assert (o.samplePeriod, o.radius, o.sampleWidth) == (1.0, 6, 6)
+
+
+def test_shipped_library_has_no_experiment_switches():
+    """Ablation / tile-variant / stamp switches exist only in the -DBHIP_EXPERIMENTS build (libboofhip_exp.so): an environment variable must
+    never be able to make a production kernel skip work.  The parity cross-check hooks (UNFUSED, NOSHARE, EXACT, ...) stay."""
+    from boofcv_amd import build
+    blob = open(build.LIB, "rb").read()
+    for name in (b"BHIP_FUSED_ABLATE", b"BHIP_FUSED_VARIANT", b"BHIP_DESCRIBE_LDSPAD", b"BHIP_DESCRIBE_STAMPS", b"BHIP_DESCRIBE_NOORDER"):
+        assert name not in blob, name
+    assert b"BHIP_DETECT_UNFUSED" in blob

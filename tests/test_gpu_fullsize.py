@@ -126,3 +126,51 @@ def test_config5_4k_pyramid_gradient_chain(api, orc):
             prev = pyr.getLayer(i - 1)
             blurred = api.BlurImageOps.gaussian(prev, None, -1, 2).array()
             assert np.abs(blurred[::2, ::2][:layer.height, :layer.width] - layer.array()).max() < 1e-3
+
+
+def test_config5_4k_device_chain(api, orc):
+    """BASELINE config 5 end to end on a device-resident 3840x2160 frame, without leaving HBM between the stages:
+    pyramid [1,2,4,8] (Gaussian r=2, PyramidDiscreteSampleBlur.java:88-118) -> Sobel of every layer (GradientSobel.java:158-173) -> |grad|^2 ->
+    strict block NMS r=2 (NonMaxBlock.java:69-94) -> Fast-Hessian + SURF-64 (stable) on layer 0.  Every stage against the oracle:
+    images and NMS lists bit-exact (lists in the reference's order), key points bit-exact, descriptors within 1e-5."""
+    torch = pytest.importorskip("torch")
+    from boofcv_amd import device as dv
+    ctx = api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream)
+    ops = dv.DeviceImageOps(ctx)
+    W, H = 3840, 2160
+    img = blobs(orc, W, H, 5000)
+    frames = torch.from_numpy(img.array().copy()).cuda().unsqueeze(0)
+    scales = [1, 2, 4, 8]
+    ker = orc.gaussian1d_f32(-1, 2)
+    layers = ops.pyramid(ker, scales, frames)
+    exp_layers, _ = orc.pyramid(ker, -1, scales, img)
+    total_nms = 0
+    for i, e in enumerate(exp_layers):
+        assert np.array_equal(bits(layers[i][0].cpu().numpy()), bits(e)), i
+        dx, dy = ops.sobel(layers[i], 0)
+        sq = ops.intensity(dv.INTENSITY_SQ, dx, dy)
+        xy, n = ops.nonmax(sq, 2, 25.0, 2)
+        ctx.synchronize()
+        ex, ey = orc.gradient("sobel", orc.Gray.from_array(e), border_zero=True)
+        assert np.array_equal(bits(dx[0].cpu().numpy()), bits(ex.array())) and np.array_equal(bits(dy[0].cpu().numpy()), bits(ey.array())), i
+        esq = ex.array() * ex.array() + ey.array() * ey.array()
+        assert np.array_equal(bits(sq[0].cpu().numpy()), bits(esq)), i
+        elist = orc.nonmax(orc.Gray.from_array(esq), 2, 25.0, 2, threads=THREADS)
+        cnt = int(n[0].item())
+        assert cnt == len(elist) and np.array_equal(xy[0, :cnt].cpu().numpy(), elist), (i, cnt, len(elist))
+        total_nms += cnt
+    assert total_nms > 1000
+    # FH + SURF on layer 0 (== the input frame), device resident
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32, ctx=ctx)
+    l0 = layers[0]
+    dd.detectDevice(l0.data_ptr(), l0.stride(0), l0.stride(1), W, H, 1)
+    ref = orc.Surf(True)
+    n = ref.detect(img, threads=THREADS)
+    xys, ang, white, desc = ref.fetch()
+    got = dd._results(0)
+    assert dd.getNumberOfFeatures() == n and n > 3000
+    assert np.array_equal(got[0], xys) and np.array_equal(got[2], white)
+    derr = np.max(np.abs(got[3] - desc), axis=1)
+    assert int((derr > 1e-5).sum()) == 0, "descriptors outside 1e-5: %d, max %.3g" % (int((derr > 1e-5).sum()), derr.max())
+    dang = np.abs(np.angle(np.exp(1j * (got[1] - ang))))
+    assert dang.max() < 1e-9, dang.max()

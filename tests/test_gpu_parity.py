@@ -1066,3 +1066,100 @@ def test_sharded_association_single_process_ranks(api, orc, kind):
             p2, f2 = eng.phase2(col_all, R, nd, p.clone(), f.clone(), b)
             torch.cuda.synchronize()
             assert np.array_equal(p2.cpu().numpy(), full_p[b:b + c]) and np.array_equal(f2.cpu().numpy(), full_f[b:b + c]), (kind, R, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------ device-batched ip front end
+@pytest.mark.parametrize("w,h,B", [(64, 40, 3), (260, 70, 2), (257, 33, 2), (1024, 37, 1), (31, 29, 2)])
+def test_device_batched_ip_ops(api, orc, w, h, B):
+    """bhip_*_dev_f32 on [B,H,W] device batches == the oracle image by image, bit for bit: tiled (16-byte aligned rows) and general
+    kernels, strided views, every border class of the normalised convolution, both gradient border policies, NMS lists in block order."""
+    torch = pytest.importorskip("torch")
+    from boofcv_amd import device as dv
+    ops = dv.DeviceImageOps(api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream))   # same stream as the torch fills below
+    frames = [orc.noise_image(w, h, 900 + b, 0, 255) for b in range(B)]
+    host = np.stack([f.array() for f in frames])
+    dense = torch.from_numpy(host).cuda()
+    # a strided view: rows padded to a multiple of 4 floats (tiled kernels) or to an odd pitch (general kernels)
+    views = [dense]
+    for pitch in ((w + 3) // 4 * 4 + 8, w + 3):
+        big = torch.full((B, h + 2, pitch), -7.0, dtype=torch.float32, device="cuda")
+        big[:, 1:h + 1, :w] = dense
+        views.append(big[:, 1:h + 1, :w])
+    torch.cuda.synchronize()
+    for src in views:
+        for r in (1, 2, 5, 6, 20):
+            k = orc.gaussian1d_f32(-1, r)
+            for kind, fn in [("h", ops.convolveHorizontal), ("v", ops.convolveVertical), ("norm_h", ops.convolveNormalizedHorizontal),
+                             ("norm_v", ops.convolveNormalizedVertical)]:
+                if not kind.startswith("norm") and len(k) > min(w, h):
+                    continue
+                out = torch.full_like(dense, 3.0)
+                fn(k, r, src, out)
+                ops.ctx.synchronize()
+                got = out.cpu().numpy()
+                for b in range(B):
+                    exp = orc.conv(kind, k, r, frames[b]).array().copy()
+                    if not kind.startswith("norm"):   # the frame keeps the caller's pixels
+                        keep = np.ones((h, w), bool)
+                        if kind == "h":
+                            keep[:, r:w - r] = False
+                        else:
+                            keep[r:h - r, :] = False
+                        exp[keep] = 3.0
+                    assert np.array_equal(bits(got[b]), bits(exp)), (kind, r, b, tuple(src.stride()))
+        k4 = np.array([0.1, 0.5, -0.2, 0.3], np.float32)   # even width, off-centre origin: the standard (not unrolled) form
+        for kind, fn in [("norm_h", ops.convolveNormalizedHorizontal), ("norm_v", ops.convolveNormalizedVertical)]:
+            got = fn(k4, 1, src)
+            ops.ctx.synchronize()
+            for b in range(B):
+                assert np.array_equal(bits(got[b].cpu().numpy()), bits(orc.conv(kind, k4, 1, frames[b]).array())), kind
+        for sigma, radius in [(-1, 2), (2.0, -1)]:
+            got = ops.gaussian(src, sigma, radius)
+            ops.ctx.synchronize()
+            for b in range(B):
+                assert np.array_equal(bits(got[b].cpu().numpy()), bits(orc.gaussian_blur(frames[b], sigma, radius).array())), (sigma, radius, b)
+        for kind, fn in [("sobel", ops.sobel), ("three", ops.three)]:
+            for border in (None, 0):
+                dx = torch.full_like(dense, 7.0); dy = torch.full_like(dense, 7.0)
+                fn(src, border, dx, dy)
+                ops.ctx.synchronize()
+                for b in range(B):
+                    ex, ey = orc.gradient(kind, frames[b], border_zero=border is not None)
+                    ex, ey = ex.array().copy(), ey.array().copy()
+                    if border is None:
+                        for e in (ex, ey):
+                            e[[0, -1], :] = 7; e[:, [0, -1]] = 7
+                    assert np.array_equal(bits(dx[b].cpu().numpy()), bits(ex)) and np.array_equal(bits(dy[b].cpu().numpy()), bits(ey)), (kind, border, b)
+    # gradient magnitude images + strict NMS lists (block-raster order) + corner intensity, per image
+    dx, dy = ops.sobel(dense, 0)
+    for kind in (dv.INTENSITY_E, dv.INTENSITY_ABS, dv.INTENSITY_SQ):
+        inten = ops.intensity(kind, dx, dy)
+        ops.ctx.synchronize()
+        gx, gy = dx.cpu().numpy(), dy.cpu().numpy()
+        exp = [np.sqrt(gx * gx + gy * gy), np.abs(gx) + np.abs(gy), gx * gx + gy * gy][kind]
+        assert np.array_equal(bits(inten.cpu().numpy()), bits(exp.astype(np.float32))), kind
+        for radius, thr, border in [(2, 100.0, 0), (1, 0.0, 3), (3, 2000.0, 1)]:
+            xy, n = ops.nonmax(inten, radius, thr, border)
+            ops.ctx.synchronize()
+            xy, n = xy.cpu().numpy(), n.cpu().numpy()
+            for b in range(B):
+                e = orc.nonmax(orc.Gray.from_array(exp[b].astype(np.float32)), radius, thr, border)
+                assert n[b] == len(e) and np.array_equal(xy[b, :n[b]], np.asarray(e, np.int16).reshape(-1, 2)), (kind, radius, b)
+    if w > 8 and h > 8:
+        for kname, kind, kappa in [("shitomasi", 0, 0.0), ("harris", 1, 0.04)]:
+            got = ops.cornerIntensity(kind, 2, kappa, dx, dy)
+            ops.ctx.synchronize()
+            for b in range(B):
+                e = orc.corner_intensity(orc.Gray.from_array(dx[b].cpu().numpy()), orc.Gray.from_array(dy[b].cpu().numpy()), 2, kname, kappa)
+                assert np.array_equal(bits(got[b].cpu().numpy()), bits(e)), (kname, b)
+    # BRIEF over the batch == per image
+    sp, cp = orc.brief_definition()
+    rng = np.random.default_rng(w * 1000 + h)
+    counts = [int(c) for c in rng.integers(0, 40, B)]
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    pts = np.stack([rng.uniform(-2, w + 2, start[-1]), rng.uniform(-2, h + 2, start[-1])], axis=1)
+    if start[-1] > 0:
+        words = ops.brief(dense, 16, sp, cp, torch.from_numpy(pts).cuda(), start).cpu().numpy()
+        for b in range(B):
+            if counts[b]:
+                assert np.array_equal(words[start[b]:start[b + 1]], orc.brief_describe(frames[b], pts[start[b]:start[b + 1]], 16, sp, cp)), b
