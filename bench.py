@@ -6,19 +6,31 @@ integral image -> Fast-Hessian detect -> orientation + SURF-64 (stable) describe
 (backwards validation on) of every frame with its successor in the batch.  Workload = BASELINE.json configs[1]
 ("Batch of 256 1920x1080 GrayF32, Fast-Hessian detect + SURF-64 describe, 1xMI355X") plus the associate leg the metric names.
 
-Multi-GPU: frames are independent units, so each rank runs its own batch (no data-path collective, "scaling": "weak");
-rank 0 prints ONE JSON line.  The line also carries
-  roofline      -- the dominant kernel's algorithmic bytes / its HIP-event time measured live in the timed region
-  cpu_baseline  -- the CPU oracle (C++ restatement of BoofCV's MT path) timed on a bounded sample of the same frames (rank 0, N=1)
+Launch: `python bench.py --gpus N` starts N rank processes itself when it is not already running under a launcher (fresh child
+processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, started BEFORE this process makes any GPU call; the parent only waits and
+relays rank 0's JSON line; a failing rank => non-zero exit).  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+the ranks come from the environment; WORLD_SIZE != --gpus is an error, never a silent single-GPU run.
+
+Workloads (--workload):
+  frames         (default) the headline metric.  Frames are independent units: each rank runs its own batch, no data-path collective,
+                 "scaling": "weak".  Rank 0 prints ONE JSON line, which also carries
+                   roofline      the dominant kernel's algorithmic bytes / its HIP-event time measured live in the timed region
+                   cpu_baseline  the CPU oracle (C++ restatement of BoofCV's MT path) on a bounded sample of the same frames (N=1 only)
+                   end_to_end    the same step through the host-buffer boundary a JNI caller uses (bhip_surf_detect_f32 -> bhip_surf_fetch ->
+                                 bhip_assoc_l2_f64): host frames in, descriptors and matches out, PCIe included (never `value`)
+  assoc_sharded  BASELINE configs[3]: one 16384 x 16384 BRIEF-512 Hamming association sharded over the ranks (boofcv_amd/sharded.py:
+                 local phase 1 -> ONE all_gather_into_tensor of the column top-2 records over RCCL -> local phase 2), "scaling": "strong"
+  chain4k        BASELINE configs[4]: 3840x2160 frames through pyramid -> Sobel -> |grad|^2 -> strict NMS per layer + Fast-Hessian/SURF on
+                 layer 0, device resident, frames sharded over the ranks ("weak")
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -26,12 +38,89 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+INT8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec); the exact-fp64 association path is VALU, not MFMA
+PCIE_GBS = 63.0  # MI355X_MICROARCH.md: host link PCIe Gen5 x16 (spec)
+MIN_TIMED_SECONDS = 3.0  # default --steps: enough steps for a timed region an external GPU-busy sampler can see
 
 
+# ---------------------------------------------------------------------------------------------------------------- launcher
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as fill %.0f s, at least 3)" % MIN_TIMED_SECONDS)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["frames", "assoc_sharded", "chain4k"], default="frames")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (frames: 256 = BASELINE config; chain4k: 8)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-boundary (PCIe-inclusive) leg")
+    ap.add_argument("--dry-launch", action="store_true", help="ranks only report their environment; no GPU call anywhere (launcher test)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Parent of a self-launched multi-GPU run.  Makes no GPU call (torch is not even imported here): starts one child per rank,
+    relays rank 0's stdout (the JSON line), forwards the other ranks' output to stderr, exits non-zero if any rank failed."""
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = str(free_port())
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [None] * n
+
+    def drain(i):
+        outs[i] = procs[i].communicate()
+
+    threads = [threading.Thread(target=drain, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    # if one rank dies the others would wait in a collective for ever: watch and terminate the exact processes we started
+    failed = False
+    while any(t.is_alive() for t in threads):
+        for p in procs:
+            rc = p.poll()
+            if rc is not None and rc != 0 and not failed:
+                failed = True
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+        time.sleep(0.2)
+    for t in threads:
+        t.join()
+    rc = 0
+    for r, p in enumerate(procs):
+        out, err = outs[r]
+        if err:
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in err.splitlines()))
+        if r == 0:
+            sys.stdout.write(out)
+        elif out:
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in out.splitlines()))
+        if p.returncode != 0:
+            rc = p.returncode or 1
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------- synthetic inputs
 def synth_frames(batch, height, width, seed0, device):
     """S-blobs(W,H,seed,n) of SURVEY 8d: background 50 + sum of n Gaussian blobs (sigma in {2,3,5,8,13,21}, amplitude +-[40,100])
     + U[0,2) noise, n ~ W*H/2000.  A blob is separable, so a frame is one [H,n]x[n,W] product."""
+    import torch
     n = max(1, (width * height) // 2000)
     sig_choices = torch.tensor([2.0, 3.0, 5.0, 8.0, 13.0, 21.0], device=device)
     xs = torch.arange(width, device=device, dtype=torch.float32)[None, :]
@@ -50,10 +139,31 @@ def synth_frames(batch, height, width, seed0, device):
     return out
 
 
+def synth_brief(n, words, seed, device):
+    """Config 4 inputs: A = random int32 words; B = A with k in 0..64 random bit flips for 75 % of the rows, fresh rows for 25 %,
+    rows shuffled.  Every rank builds the same sets from the same seed."""
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    a = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, words), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    flips = torch.randint(0, 65, (n,), device=device, generator=g)
+    bitpos = torch.rand((n, words * 32), device=device, generator=g).argsort(dim=1)
+    mask_bits = (torch.arange(words * 32, device=device)[None, :] < flips[:, None])
+    flipbits = torch.zeros((n, words * 32), dtype=torch.bool, device=device)
+    flipbits.scatter_(1, bitpos, mask_bits)
+    w = (flipbits.view(n, words, 32).long() << torch.arange(32, device=device)[None, None, :]).sum(dim=2)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+    b = a ^ w
+    b[-(n // 4):] = torch.randint(-2 ** 31, 2 ** 31 - 1, (n // 4, words), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    b = b[torch.randperm(n, device=device, generator=g)].contiguous()
+    return a, b
+
+
+# ---------------------------------------------------------------------------------------------------------------- the hot path
 class HotPath:
     """detect + describe + associate over a device-resident batch, through the C ABI only."""
 
     def __init__(self, device_index, batch, height, width):
+        import torch
         from boofcv_amd import api, _lib
         self.api, self._lib = api, _lib
         self.L = _lib.load()
@@ -66,6 +176,8 @@ class HotPath:
 
     def step(self, frames):
         import ctypes as C
+        import numpy as np
+        import torch
         B = self.batch
         self.dd.detectDevice(frames.data_ptr(), self.h * self.w, self.w, self.w, self.h, B)
         total = self.dd.totalFeatures()
@@ -89,6 +201,64 @@ class HotPath:
         if st != 0:
             raise RuntimeError("bhip_assoc_l2_dev_batched failed: %s" % self.L.bhip_last_error(self.ctx._h))
         return total
+
+
+class HostBoundary:
+    """The same step through the host-buffer entry points a JNI shim binds: frames in pinned host memory ->
+    bhip_surf_detect_f32 (sub-batches) -> bhip_surf_fetch per frame (location, orientation, sign, descriptor to host) ->
+    bhip_assoc_l2_f64 per consecutive pair (host descriptors in, matches out).  Two host threads, each with its own ctx / stream /
+    detector, take alternate sub-batches so the upload of one overlaps the kernels of the other."""
+
+    def __init__(self, device_index, frames_host, sub_batch):
+        import numpy as np
+        from boofcv_amd import api
+        self.api = api
+        self.np = np
+        self.dev = device_index
+        self.frames = frames_host      # pinned [B,H,W] float32 numpy view
+        self.B, self.h, self.w = frames_host.shape
+        self.sub = sub_batch
+        self.workers = []
+        for _ in range(2):
+            ctx = api.Context(device_index)
+            dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32, ctx=ctx)
+            assoc = api.FactoryAssociation.greedy(api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True, ctx=ctx)
+            self.workers.append((ctx, dd, assoc))
+        self.desc = [None] * self.B
+        self.matches = 0
+
+    def _detect_range(self, widx, chunks):
+        api = self.api
+        ctx, dd, _ = self.workers[widx]
+        for (a, b) in chunks:
+            imgs = [api.GrayF32(self.w, self.h, self.frames[i].reshape(-1)) for i in range(a, b)]
+            dd.detectBatch(imgs)
+            for j in range(b - a):
+                self.desc[a + j] = dd._results(j)[3]    # bhip_surf_fetch: xy/scale, angle, sign, descriptors to host
+
+    def _assoc_range(self, widx, idx):
+        _, _, assoc = self.workers[widx]
+        m = 0
+        for i in idx:
+            assoc.setSource(self.desc[i]); assoc.setDestination(self.desc[(i + 1) % self.B]); assoc.associate()
+            m += int((assoc.getPairs() >= 0).sum())
+        self._m[widx] = m
+
+    def step(self):
+        chunks = [(a, min(a + self.sub, self.B)) for a in range(0, self.B, self.sub)]
+        ts = [threading.Thread(target=self._detect_range, args=(w, chunks[w::2])) for w in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        self._m = [0, 0]
+        ts = [threading.Thread(target=self._assoc_range, args=(w, range(w, self.B, 2))) for w in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        self.matches = sum(self._m)
+        return sum(len(d) for d in self.desc)
 
 
 def pmc_traffic(tag, batch, height, width):
@@ -126,112 +296,365 @@ def cpu_baseline(frames_cpu, threads):
     return n / dt, dt, [len(d) for d in descs]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (BASELINE config: 256)")
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
-    args = ap.parse_args()
+class Dist:
+    """rank plumbing: torch.distributed over RCCL ("nccl") when WORLD_SIZE > 1"""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
 
-    B, H, W = args.batch, args.height, args.width
-    frames = synth_frames(B, H, W, 1000 + rank * B, device)
-    torch.cuda.synchronize()
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    hp = HotPath(local_rank, B, H, W)
+    def max(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def sum(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def ranks_seen(self):
+        return self.dist.get_world_size() if self.dist is not None else 1
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(D, args, step_fn):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; elapsed = MAX over ranks.
+    K = --steps, or (when not given) the number of steps that fills MIN_TIMED_SECONDS, agreed across ranks."""
+    torch = D.torch
+    result = None
+    for _ in range(max(args.warmup, 0)):
+        result = step_fn()
+    steps = args.steps
+    if steps is None:
+        D.barrier()
+        t0 = time.perf_counter()
+        result = step_fn()
         torch.cuda.synchronize()
+        one = D.max(time.perf_counter() - t0)
+        steps = max(3, int(MIN_TIMED_SECONDS / max(one, 1e-6)) + 1)
+        steps = int(D.max(float(steps)))
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        result = step_fn()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max(time.perf_counter() - t0)
+    return steps, elapsed, result
 
-    kp_total = 0
-    for _ in range(args.warmup):
-        kp_total = hp.step(frames)
-    barrier()
+
+# ---------------------------------------------------------------------------------------------------------------- workload: frames
+def run_frames(args, D):
+    import numpy as np
+    torch = D.torch
+    B = args.batch or 256
+    H = args.height or 1080
+    W = args.width or 1920
+    frames = synth_frames(B, H, W, 1000 + D.rank * B, D.device)
+    torch.cuda.synchronize()
+    hp = HotPath(D.local_rank, B, H, W)
+
+    kp = [0]
+
+    def step():
+        kp[0] = hp.step(frames)
+        return kp[0]
+
+    for _ in range(max(args.warmup, 0)):
+        step()
+    warm = args.warmup
+    args.warmup = 0
     hp.ctx.profile(True)
     hp.ctx.profileReset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kp_total = hp.step(frames)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if args.steps is None:   # calibration step runs with profiling on too; reset after it
+        D.barrier()
+        t0 = time.perf_counter(); step(); torch.cuda.synchronize()
+        one = D.max(time.perf_counter() - t0)
+        args.steps = int(D.max(float(max(3, int(MIN_TIMED_SECONDS / max(one, 1e-6)) + 1))))
+        hp.ctx.profileReset()
+    steps, elapsed, _ = timed_steps(D, args, step)
+    args.warmup = warm
     prof = hp.ctx.profileReport()
     hp.ctx.profile(False)
+    kp_all = D.sum(float(kp[0]))
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kp_total], dtype=torch.float64, device=device)
-        dist.all_reduce(k, op=dist.ReduceOp.SUM)
-        kp_all = float(k.item())
-    else:
-        kp_all = float(kp_total)
+    # host-boundary leg (every rank runs it at the same time: the ranks share the host's PCIe complex and cores)
+    e2e = None
+    if not args.no_end_to_end:
+        host = torch.empty((B, H, W), dtype=torch.float32, pin_memory=True)
+        host.copy_(frames)
+        torch.cuda.synchronize()
+        hb = HostBoundary(D.local_rank, host.numpy(), sub_batch=min(32, B))
+        hb.step()   # warm-up: allocations, first-touch
+        D.barrier()
+        reps = 2 if B >= 64 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            kp_e2e = hb.step()
+        D.barrier()
+        dt = D.max(time.perf_counter() - t0)
+        desc_bytes = kp_e2e * (64 * 8 + 3 * 8 + 8 + 1)
+        h2d = B * H * W * 4 + 2 * kp_e2e * 64 * 8          # frames + both descriptor sets of every association
+        d2h = desc_bytes + kp_e2e * 12
+        e2e = {"value": round(D.world * B * reps / dt, 1), "unit": "frames/s", "ms_per_batch": round(1e3 * dt / reps, 2),
+               "path": "bhip_surf_detect_f32 (pinned host frames, sub-batches of %d, 2 host threads / streams) + bhip_surf_fetch per frame + "
+                       "bhip_assoc_l2_f64 per consecutive pair" % hb.sub,
+               "h2d_bytes_per_frame": int(h2d / B), "d2h_bytes_per_frame": int(d2h / B),
+               "pcie_ceiling_frames_per_s": round(PCIE_GBS * 1e9 / (h2d / B), 1), "pcie_peak_GBs": PCIE_GBS,
+               "matches_per_frame": round(hb.matches / B, 1)}
+        del hb
 
-    if rank == 0:
-        frames_total = world * B * args.steps
-        value = frames_total / elapsed
-        # dominant kernel by accumulated HIP-event time inside the timed region
-        roofline = None
-        if prof:
-            dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-            tag, r = dom
-            per_launch_s = r["ms"] / r["launches"] / 1e3
-            if r["bytes"] > 0:
-                achieved = r["bytes"] / r["launches"] / per_launch_s / 1e9
-                roofline = {"kernel": tag, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                            "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"]}
-            else:
-                # not an HBM-roofline kernel (gather + fp64 VALU per key point): report against the fp64 vector peak when flops are known
-                achieved = (r["flops"] / r["launches"] / per_launch_s / 1e12) if r["flops"] > 0 else 0.0
-                peak = FP32_MFMA_PEAK_TFLOPS if "mfma" in tag else FP64_VECTOR_PEAK_TFLOPS
-                roofline = {"kernel": tag, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
-                            "frac": round(achieved / peak, 4), "traffic": None,
-                            "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"]}
-            tb, src = pmc_traffic(tag, B, H, W)
-            if tb is not None:
-                roofline["traffic"] = tb
-                roofline["traffic_note"] = "bytes per launch leaving the XCD L2s (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC), from " + src
-                roofline["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["launches"]) if r["bytes"] > 0 else None
-            roofline["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-            roofline["hbm_gbs_by_kernel"] = {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}
-            roofline["tflops_by_kernel"] = {k: round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}
-        cpu = None
-        if world == 1 and args.cpu_frames > 0:
-            threads = min(os.cpu_count() or 1, 16)
-            sample = frames[:args.cpu_frames].cpu().numpy()
-            fps, dt, kps = cpu_baseline(sample, threads)
-            cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-                   "sample": "%d of the same %dx%d frames, detect+describe+associate(next frame), %.1f s of CPU work, %.0f key points/frame" % (len(sample), W, H, dt, float(np.mean(kps)))}
-        line = {
-            "metric": "1080p frames/sec detect+describe+associate", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 detect / f64 describe+associate", "data": "synthetic",
-            "config": {"workload": "batch of %d %dx%d GrayF32 per GPU: Fast-Hessian detect + SURF-64 (stable) describe + greedy L2 associate with the next frame"
-                                   % (B, W, H), "batch_per_gpu": B, "width": W, "height": H, "keypoints_per_frame": round(kp_all / (world * B), 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if D.rank != 0:
+        return None
+    frames_total = D.world * B * steps
+    value = frames_total / elapsed
+    roofline = None
+    if prof:
+        tag, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_s = r["ms"] / r["launches"] / 1e3
+        if r["bytes"] > 0:
+            achieved = r["bytes"] / r["launches"] / per_launch_s / 1e9
+            roofline = {"kernel": tag, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"],
+                        "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"])}
+        else:
+            achieved = (r["flops"] / r["launches"] / per_launch_s / 1e12) if r["flops"] > 0 else 0.0
+            peak = FP32_MFMA_PEAK_TFLOPS if "mfma" in tag else FP64_VECTOR_PEAK_TFLOPS
+            roofline = {"kernel": tag, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"]}
+        tb, src = pmc_traffic(tag, B, H, W)
+        if tb is not None:
+            roofline["traffic"] = tb
+            roofline["traffic_note"] = "bytes per launch leaving the XCD L2s (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 PMC), from " + src
+            roofline["hbm_frac_from_traffic"] = round(tb / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)
+        if tag == "k_describe":
+            # SURVEY 8d: a gather stage.  `achieved` follows the contract (algorithmic tap bytes / time) but nearly all of those bytes are
+            # served by L1/L2: what limits the kernel is instruction issue (profiles/*_pmc_insts.txt), not HBM.
+            roofline["limiter"] = "valu-issue (cache-served gathers; see hbm_frac_from_traffic for the bytes that reach HBM)"
+        roofline["kernels_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        roofline["hbm_gbs_by_kernel"] = {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}
+        roofline["tflops_by_kernel"] = {k: round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}
+        # the detect stage as a whole (a1-a4) against its HBM roofline: SURVEY 8d's 66.5 * P bytes per frame
+        det_ms = sum(v["ms"] for k, v in prof.items() if k.startswith(("k_integral", "k_detect_fused", "k_hessian", "k_nms", "k_word_prefix", "k_rank_scatter")))
+        if det_ms > 0:
+            det_gbs = 66.5 * W * H * B * steps / (det_ms / 1e3) / 1e9
+            roofline["detect_stage"] = {"ms_per_step": round(det_ms / steps, 3), "algorithmic_GBs": round(det_gbs, 1), "frac": round(det_gbs / HBM_PEAK_GBS, 4)}
+    cpu = None
+    if D.world == 1 and args.cpu_frames > 0:
+        threads = min(os.cpu_count() or 1, 16)
+        sample = frames[:args.cpu_frames].cpu().numpy()
+        fps, dt, kps = cpu_baseline(sample, threads)
+        cpu = {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+               "sample": "%d of the same %dx%d frames, detect+describe+associate(next frame), %.1f s of CPU work, %.0f key points/frame" % (len(sample), W, H, dt, float(np.mean(kps)))}
+    return {
+        "metric": "1080p frames/sec detect+describe+associate", "value": round(value, 2), "unit": "frames/s", "n_gpus": D.world,
+        "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 detect / f64 describe+associate", "data": "synthetic",
+        "config": {"workload": "batch of %d %dx%d GrayF32 per GPU: Fast-Hessian detect + SURF-64 (stable) describe + greedy L2 associate with the next frame"
+                               % (B, W, H), "batch_per_gpu": B, "width": W, "height": H, "keypoints_per_frame": round(kp_all / (D.world * B), 1),
+                   "ranks_seen": D.ranks_seen()},
+        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------- workload: assoc_sharded
+def run_assoc_sharded(args, D):
+    torch = D.torch
+    from boofcv_amd import sharded, api
+    n, words = 16384, 16
+    a, b = synth_brief(n, words, 4, D.device)
+    part = sharded.row_partition(n, D.world)
+    begin, count = part[D.rank]
+    src_local = a[begin:begin + count].contiguous()
+    eng = sharded.GpuEngine(device=D.local_rank)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    gather_ms = [0.0]
+    res = [None]
+
+    def step():
+        # the same orchestration as sharded.associate_sharded, with events around the one exchange step
+        pairs, fit, col = eng.phase1("hamming", src_local, begin, b, api.Double_MAX_VALUE)
+        if D.world > 1:
+            col_all = torch.empty(D.world * col.numel(), dtype=torch.uint8, device=col.device)
+            ev[0].record()
+            D.dist.all_gather_into_tensor(col_all, col.contiguous())
+            ev[1].record()
+        else:
+            col_all = col
+        res[0] = eng.phase2(col_all, D.world, n, pairs, fit, begin)
+        if D.world > 1:
+            ev[1].synchronize()
+            gather_ms[0] += ev[0].elapsed_time(ev[1])
+        return res[0]
+
+    for _ in range(max(args.warmup, 0)):
+        step()
+    warm = args.warmup
+    args.warmup = 0
+    gather_ms[0] = 0.0
+    eng.ctx.profile(True); eng.ctx.profileReset()
+    if args.steps is None:
+        D.barrier()
+        t0 = time.perf_counter(); step(); torch.cuda.synchronize()
+        one = D.max(time.perf_counter() - t0)
+        args.steps = int(D.max(float(max(3, int(MIN_TIMED_SECONDS / max(one, 1e-6)) + 1))))
+        gather_ms[0] = 0.0
+        eng.ctx.profileReset()
+    steps, elapsed, _ = timed_steps(D, args, step)
+    args.warmup = warm
+    prof = eng.ctx.profileReport(); eng.ctx.profile(False)
+    matched = D.sum(float((res[0][0] >= 0).sum().item()))
+    gather = D.max(gather_ms[0] / steps)
+    if D.rank != 0:
+        return None
+    ms = 1e3 * elapsed / steps
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+    roofline = None
+    if dom:
+        tag, r = dom
+        per_launch_s = r["ms"] / r["launches"] / 1e3
+        tops = r["flops"] / r["launches"] / per_launch_s / 1e12 if r["flops"] > 0 else 0.0
+        roofline = {"kernel": tag, "bound": "mfma", "achieved": round(tops, 2), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s (int8)",
+                    "frac": round(tops / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"],
+                    "kernels_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+    return {
+        "metric": "BRIEF-512 16384x16384 Hamming associations/s (sharded over the ranks)", "value": round(steps / elapsed, 2), "unit": "associations/s",
+        "n_gpus": D.world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u32 popcount as int8 MFMA", "data": "synthetic",
+        "config": {"workload": "one 16384x16384 BRIEF-512 greedy Hamming association with backwards validation; rank r owns %d source rows and the whole "
+                               "destination set; one all_gather_into_tensor of 16384 24-byte column records per rank" % part[0][1],
+                   "ranks_seen": D.ranks_seen(), "all_gather_ms": round(gather, 4), "all_gather_share": round(gather / ms, 4) if ms > 0 else None,
+                   "matched": int(matched)},
+        "roofline": roofline, "cpu_baseline": None,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------- workload: chain4k
+def run_chain4k(args, D):
+    import numpy as np
+    torch = D.torch
+    from boofcv_amd import api, device as dv
+    B = args.batch or 8
+    H = args.height or 2160
+    W = args.width or 3840
+    frames = synth_frames(B, H, W, 5000 + D.rank * B, D.device)
+    ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream(D.local_rank).cuda_stream)
+    ops = dv.DeviceImageOps(ctx)
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32, ctx=ctx)
+    ker = api.FactoryKernelGaussian.gaussian1D_F32(-1, 2).data
+    scales = [1, 2, 4, 8]
+    dims, offs, total = ops.pyramidLayout(W, H, scales)
+    # every buffer of the chain is allocated once: steps reuse them, as a streaming caller would
+    bufs = {"dx": [], "dy": [], "sq": []}
+    for (w, h) in dims:
+        for k in bufs:
+            bufs[k].append(torch.empty((B, int(h), int(w)), dtype=torch.float32, device=D.device))
+    counts = [0, 0]
+
+    def step():
+        layers = ops.pyramid(ker, scales, frames)
+        nms = 0
+        ns = []
+        for i, layer in enumerate(layers):
+            ops.sobel(layer, 0, bufs["dx"][i], bufs["dy"][i])
+            ops.intensity(dv.INTENSITY_SQ, bufs["dx"][i], bufs["dy"][i], bufs["sq"][i])
+            xy, n = ops.nonmax(bufs["sq"][i], 2, 25.0, 2)
+            ns.append(n)
+        l0 = layers[0]
+        dd.detectDevice(l0.data_ptr(), l0.stride(0), l0.stride(1), W, H, B)
+        counts[0] = dd.totalFeatures()
+        counts[1] = int(torch.stack([n.sum() for n in ns]).sum().item())
+        return counts[0]
+
+    for _ in range(max(args.warmup, 0)):
+        step()
+    warm = args.warmup
+    args.warmup = 0
+    ctx.profile(True); ctx.profileReset()
+    if args.steps is None:
+        D.barrier()
+        t0 = time.perf_counter(); step(); torch.cuda.synchronize()
+        one = D.max(time.perf_counter() - t0)
+        args.steps = int(D.max(float(max(3, int(MIN_TIMED_SECONDS / max(one, 1e-6)) + 1))))
+        ctx.profileReset()
+    steps, elapsed, _ = timed_steps(D, args, step)
+    args.warmup = warm
+    prof = ctx.profileReport(); ctx.profile(False)
+    kp_all = D.sum(float(counts[0]))
+    nms_all = D.sum(float(counts[1]))
+    if D.rank != 0:
+        return None
+    tag, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_s = r["ms"] / r["launches"] / 1e3
+    achieved = r["bytes"] / r["launches"] / per_launch_s / 1e9 if r["bytes"] > 0 else 0.0
+    roofline = {"kernel": tag, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"],
+                "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                "hbm_gbs_by_kernel": {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}}
+    return {
+        "metric": "3840x2160 frames/sec pyramid+gradient+NMS+SURF chain", "value": round(D.world * B * steps / elapsed, 2), "unit": "frames/s", "n_gpus": D.world,
+        "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 pyramid/gradient/detect, f64 describe", "data": "synthetic",
+        "config": {"workload": "batch of %d %dx%d GrayF32 per GPU, device resident: pyramid [1,2,4,8] (Gaussian r=2) -> Sobel -> |grad|^2 -> strict NMS r=2 on every "
+                               "layer, Fast-Hessian + SURF-64 (stable) on layer 0" % (B, W, H), "batch_per_gpu": B, "width": W, "height": H,
+                   "keypoints_per_frame": round(kp_all / (D.world * B), 1), "nms_maxima_per_frame": round(nms_all / (D.world * B), 1), "ranks_seen": D.ranks_seen()},
+        "roofline": roofline, "cpu_baseline": None,
+    }
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not under_launcher and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))      # no GPU call has been made in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a number for the wrong GPU count\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.dry_launch:
+        line = {"dry_launch": True, "rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world_size": world, "n_gpus": args.gpus,
+                "master": "%s:%s" % (os.environ.get("MASTER_ADDR", ""), os.environ.get("MASTER_PORT", "")), "pid": os.getpid()}
+        # rank 0's line goes to stdout (relayed by the parent); the others identify themselves on stderr
+        (sys.stdout if rank == 0 else sys.stderr).write(json.dumps(line) + "\n")
+        return
+    D = Dist(args)
+    line = {"frames": run_frames, "assoc_sharded": run_assoc_sharded, "chain4k": run_chain4k}[args.workload](args, D)
+    if D.rank == 0:
+        assert line["n_gpus"] == args.gpus
+        print(json.dumps(line), flush=True)
+    D.close()
 
 
 if __name__ == "__main__":

@@ -102,6 +102,14 @@ class Context:
 # ------------------------------------------------------------------------------------------------------------------
 # data types
 # ------------------------------------------------------------------------------------------------------------------
+def _check_extent(width, height, startIndex, stride, size):
+    """The raw pointer goes to the C ABI: the view must lie inside its array (a Java array access would throw instead of reading past the end)."""
+    if width < 0 or height < 0 or startIndex < 0 or stride < width:
+        raise IllegalArgumentException("bad image geometry: width %d height %d startIndex %d stride %d" % (width, height, startIndex, stride))
+    if width > 0 and height > 0 and startIndex + (height - 1) * stride + width > size:
+        raise IllegalArgumentException("image view (startIndex %d, stride %d, %d x %d) exceeds its data array of %d elements" % (startIndex, stride, width, height, size))
+
+
 class GrayF32:
     """T:struct/image/GrayF32.java:30 / ImageBase.java:34-52: pixel (x,y) = data[startIndex + y*stride + x]."""
 
@@ -113,6 +121,7 @@ class GrayF32:
             data = np.zeros(self.startIndex + self.stride * self.height, dtype=np.float32)
         if data.dtype != np.float32 or not data.flags["C_CONTIGUOUS"] or data.ndim != 1:
             raise IllegalArgumentException("data must be a contiguous 1-D float32 array")
+        _check_extent(self.width, self.height, self.startIndex, self.stride, data.size)
         self.data = data
 
     @staticmethod
@@ -127,6 +136,8 @@ class GrayF32:
         self.width, self.height, self.stride = int(width), int(height), int(width)
 
     def subimage(self, x0, y0, x1, y1):
+        if not (0 <= x0 <= x1 <= self.width and 0 <= y0 <= y1 <= self.height):   # ImageBase.subimage throws IllegalArgumentException
+            raise IllegalArgumentException("sub-image (%d,%d)-(%d,%d) is outside the %d x %d image" % (x0, y0, x1, y1, self.width, self.height))
         return GrayF32(x1 - x0, y1 - y0, self.data, self.startIndex + y0 * self.stride + x0, self.stride)
 
     def array(self):
@@ -183,6 +194,7 @@ class _GrayInt:
             data = np.zeros(self.startIndex + self.stride * self.height, dtype=self.dtype)
         if data.dtype != self.dtype or not data.flags["C_CONTIGUOUS"] or data.ndim != 1:
             raise IllegalArgumentException("data must be a contiguous 1-D %s array" % np.dtype(self.dtype).name)
+        _check_extent(self.width, self.height, self.startIndex, self.stride, data.size)
         self.data = data
 
     @classmethod
@@ -197,6 +209,8 @@ class _GrayInt:
         self.width, self.height, self.stride = int(width), int(height), int(width)
 
     def subimage(self, x0, y0, x1, y1):
+        if not (0 <= x0 <= x1 <= self.width and 0 <= y0 <= y1 <= self.height):
+            raise IllegalArgumentException("sub-image (%d,%d)-(%d,%d) is outside the %d x %d image" % (x0, y0, x1, y1, self.width, self.height))
         return type(self)(x1 - x0, y1 - y0, self.data, self.startIndex + y0 * self.stride + x0, self.stride)
 
     def array(self):
@@ -422,6 +436,8 @@ class DetectDescribePoint:
         for im in images:
             if im.width != w or im.height != h:
                 raise IllegalArgumentException("all images of a batch must have the same shape")
+        for im in images:
+            _check_extent(im.width, im.height, im.startIndex, im.stride, im.data.size)   # the fields are mutable: validate what is handed over
         n = len(images)
         u8 = isinstance(images[0], GrayU8)
         if any(isinstance(im, GrayU8) != u8 for im in images):
@@ -435,6 +451,7 @@ class DetectDescribePoint:
         _check(self.ctx, fn(self._h, ptrs, starts, strides, w, h, n))
         self._batch = n
         self._image = 0
+        self._shape = (w, h)
 
     def detectDevice(self, dev_ptr, imageStride, stride, width, height, batch):
         """Batch already resident in HBM (bench path): dev_ptr is a device address of float32 pixels."""
@@ -443,6 +460,7 @@ class DetectDescribePoint:
         _check(self.ctx, _lib.load().bhip_surf_detect_dev_f32(self._h, C.c_void_p(dev_ptr), imageStride, stride, width, height, batch))
         self._batch = batch
         self._image = 0
+        self._shape = (width, height)
 
     def selectImage(self, image):
         """Which image of the last batch the index-based getters refer to (0 for the single-image reference call)."""
@@ -484,8 +502,13 @@ class DetectDescribePoint:
                                                               white.ctypes.data_as(_lib._u8p), desc.ctypes.data_as(_lib._dp)))
         return ang, white, desc
 
-    def fetchIntegral(self, image, width, height):
-        out = np.zeros((height, width), dtype=np.float32)
+    def fetchIntegral(self, image, width=None, height=None):
+        """Integral image of image `image` of the last detect.  The buffer is sized from the detector's own shape (the C side copies
+        W*H words of the last detect); width / height, when given, must agree with it."""
+        w, h = self._shape
+        if (width is not None and width != w) or (height is not None and height != h):
+            raise IllegalArgumentException("the last detect ran on %d x %d images, not %s x %s" % (w, h, width, height))
+        out = np.zeros((h, w), dtype=np.float32)
         _check(self.ctx, _lib.load().bhip_surf_fetch_integral(self._h, image, out.ctypes.data_as(_lib._fp)))
         return out
 
@@ -534,9 +557,12 @@ class SurfPlanar_to_DetectDescribePoint(DetectDescribePoint):
         ptrs = (C.POINTER(C.c_float) * self.numBands)(*[b._p() for b in input.bands])
         self._cache = {}
         self._batch = 0
+        for b in input.bands:
+            _check_extent(input.width, input.height, b.startIndex, b.stride, b.data.size)
         _check(self.ctx, _lib.load().bhip_surf_detect_planar_f32(self._h, ptrs, self.numBands, b0.startIndex, b0.stride, input.width, input.height))
         self._batch = 1
         self._image = 0
+        self._shape = (input.width, input.height)
 
     def detectBatch(self, images):
         raise RuntimeError("colour SURF processes one planar frame per call")
@@ -1040,6 +1066,8 @@ class Kernel1D_F32:
 
 def _conv(fn, kernel, src, dst, ctx):
     ctx = _ctx(ctx)
+    for im in (src, dst):
+        _check_extent(im.width, im.height, im.startIndex, im.stride, im.data.size)
     if dst.width != src.width or dst.height != src.height:
         raise IllegalArgumentException("Image shapes do not match")  # InputSanityCheck.checkSameShape
     _check(ctx, fn(ctx._h, kernel.data.ctypes.data_as(_lib._fp), kernel.width, kernel.offset, src._p(), src.startIndex, src.stride, src.width, src.height,

@@ -235,6 +235,111 @@ __global__ __launch_bounds__(256) void k_conv_v_tile(ConvParams P) {
 	}
 }
 
+// ---- streaming forms for the reference's unrolled widths (3..11, centred): no LDS, every input row loaded once per strip ----
+// Horizontal: lane l owns columns 4l..4l+3 of a 256-column strip and walks CS_ROWS rows; a row's taps are NL aligned 16-byte loads
+// (own chunk + the chunks the kernel reaches into; neighbouring lanes' chunks are L1 hits), results leave as one 16-byte store.
+#define CS_ROWS 16
+template <int KW>
+__global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
+	constexpr int R = KW / 2, NC = (R + 3) / 4, NL = 1 + 2 * NC, PL = 4 * NC;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;
+	const int y0 = (blockIdx.y * 4 + wave) * CS_ROWS;
+	if (x >= P.width || y0 >= P.height) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride;
+	const int yEnd = min(y0 + CS_ROWS, P.height);
+	const bool allInterior = x >= R && x + 3 < P.width - R && P.mode != 3;
+	if (!allInterior) {
+		// strips that touch the left / right border (or hold the row's tail): the general per-pixel rules, taps through L1
+		for (int y = y0; y < yEnd; y++) {
+			const float* row = img + (long long)y * P.inStride;
+			float* dst = outImg + (long long)y * P.outStride + x;
+			for (int j = 0; j < 4 && x + j < P.width; j++) {
+				float r;
+				if (convOne<KW>(P, row + x + j - R, 1, x + j, P.width, r)) dst[j] = r;
+			}
+		}
+		return;
+	}
+	for (int y = y0; y < yEnd; y++) {
+		const float* row = img + (long long)y * P.inStride;
+		float v[4 * NL];
+#pragma unroll
+		for (int c = 0; c < NL; c++) {
+			const float4 q = loadRow4(row, x - PL + 4 * c, P.width);
+			v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+		}
+		float r[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			float total = v[PL - R + j] * P.k[0];
+#pragma unroll
+			for (int i = 1; i < KW; i++) total += v[PL - R + j + i] * P.k[i];
+			r[j] = total;
+		}
+		*reinterpret_cast<float4*>(outImg + (long long)y * P.outStride + x) = make_float4(r[0], r[1], r[2], r[3]);
+	}
+}
+
+// Vertical: lane l owns columns 4l..4l+3 and walks a strip of CS_ROWS_V output rows with the KW input rows of the current output in a
+// register ring of KW+1 slots (the extra slot receives the next row while the current output is computed).  Strips that touch the top or
+// bottom border evaluate the border rules per row from the same ring.
+#define CS_ROWS_V 32
+template <int KW>
+__global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
+	constexpr int R = KW / 2, RING = KW + 1;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;
+	const int y0 = (blockIdx.y * 4 + wave) * CS_ROWS_V;
+	if (x >= P.width || y0 >= P.height) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride + x;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride + x;
+	const int yEnd = min(y0 + CS_ROWS_V, P.height);
+	const bool full4 = x + 3 < P.width;
+	auto loadRow = [&](int yy) -> float4 {
+		if (yy < 0 || yy >= P.height) return make_float4(0, 0, 0, 0);
+		return loadRow4(img + (long long)yy * P.inStride - x, x, P.width);
+	};
+	const bool interiorStrip = y0 >= R && yEnd + R <= P.height && P.mode != 3;
+	if (!interiorStrip) {
+		// top / bottom strips: the general per-pixel rules, taps through L1
+		for (int y = y0; y < yEnd; y++) {
+			float* dst = outImg + (long long)y * P.outStride;
+			for (int q = 0; q < 4 && x + q < P.width; q++) {
+				float r;
+				if (convOne<KW>(P, img + (long long)(y - R) * P.inStride + q, P.inStride, y, P.height, r)) dst[q] = r;
+			}
+		}
+		return;
+	}
+	float4 ring[RING];
+	// ring[(t + i) % RING] = input row y0 - R + t + i, the tap i of output row y0 + t
+#pragma unroll
+	for (int i = 0; i < KW - 1; i++) ring[i] = loadRow(y0 - R + i);
+	for (int tb = 0; y0 + tb < yEnd; tb += RING) {
+#pragma unroll
+		for (int j = 0; j < RING; j++) {
+			const int y = y0 + tb + j;
+			if (y < yEnd) {
+				ring[(j + KW - 1) % RING] = loadRow(y + R);
+				float r[4];
+				const float4 t0 = ring[j % RING];
+				r[0] = t0.x * P.k[0]; r[1] = t0.y * P.k[0]; r[2] = t0.z * P.k[0]; r[3] = t0.w * P.k[0];
+#pragma unroll
+				for (int i = 1; i < KW; i++) {
+					const float4 t = ring[(j + i) % RING];
+					r[0] += t.x * P.k[i]; r[1] += t.y * P.k[i]; r[2] += t.z * P.k[i]; r[3] += t.w * P.k[i];
+				}
+				float* dst = outImg + (long long)y * P.outStride;
+				if (full4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+				else
+					for (int q = 0; q < 4 && x + q < P.width; q++) dst[q] = r[q];
+			}
+		}
+	}
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
@@ -273,6 +378,23 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 		dim3 grid((width + 255) / 256, height, batch);
 		if (vertical) hipLaunchKernelGGL(k_conv<true>, grid, dim3(256), 0, ctx->stream, P);
 		else hipLaunchKernelGGL(k_conv<false>, grid, dim3(256), 0, ctx->stream, P);
+	} else if (P.unrolled) {
+		// the reference's unrolled widths: register-streaming kernels
+		const int rows = vertical ? CS_ROWS_V : CS_ROWS;
+		dim3 grid((width + 255) / 256, (height + 4 * rows - 1) / (4 * rows), batch);
+#define LAUNCH_S(KWT)                                                                                      \
+	do {                                                                                                   \
+		if (vertical) hipLaunchKernelGGL(k_conv_v_stream<KWT>, grid, dim3(256), 0, ctx->stream, P);        \
+		else hipLaunchKernelGGL(k_conv_h_stream<KWT>, grid, dim3(256), 0, ctx->stream, P);                 \
+	} while (0)
+		switch (kw) {
+		case 3: LAUNCH_S(3); break;
+		case 5: LAUNCH_S(5); break;
+		case 7: LAUNCH_S(7); break;
+		case 9: LAUNCH_S(9); break;
+		default: LAUNCH_S(11); break;
+		}
+#undef LAUNCH_S
 	} else if (vertical) {
 		dim3 grid((width + CT_W - 1) / CT_W, (height + CV_ROWS - 1) / CV_ROWS, batch);
 		const size_t ldsBytes = (size_t)(CV_ROWS + kw - 1) * CT_W * 4;
@@ -281,12 +403,7 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 		if (ldsBytes > 65536) BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_conv_v_tile<KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
 		hipLaunchKernelGGL(k_conv_v_tile<KWT>, grid, dim3(256), ldsBytes, ctx->stream, P);                              \
 	} while (0)
-		if (P.unrolled && kw == 3) LAUNCH_V(3);
-		else if (P.unrolled && kw == 5) LAUNCH_V(5);
-		else if (P.unrolled && kw == 7) LAUNCH_V(7);
-		else if (P.unrolled && kw == 9) LAUNCH_V(9);
-		else if (P.unrolled && kw == 11) LAUNCH_V(11);
-		else LAUNCH_V(0);
+		LAUNCH_V(0);
 #undef LAUNCH_V
 	} else {
 		const int offR = kw - koff - 1;
@@ -295,12 +412,7 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 		dim3 grid((width + CT_W - 1) / CT_W, (height + CT_ROWS - 1) / CT_ROWS, batch);
 		const size_t ldsBytes = (size_t)CT_ROWS * ldsRow * 4;
 #define LAUNCH_H(KWT) hipLaunchKernelGGL(k_conv_h_tile<KWT>, grid, dim3(256), ldsBytes, ctx->stream, P, padL, ldsRow)
-		if (P.unrolled && kw == 3) LAUNCH_H(3);
-		else if (P.unrolled && kw == 5) LAUNCH_H(5);
-		else if (P.unrolled && kw == 7) LAUNCH_H(7);
-		else if (P.unrolled && kw == 9) LAUNCH_H(9);
-		else if (P.unrolled && kw == 11) LAUNCH_H(11);
-		else LAUNCH_H(0);
+		LAUNCH_H(0);
 #undef LAUNCH_H
 	}
 	BHIP_HIP(ctx, hipGetLastError());

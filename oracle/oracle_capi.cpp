@@ -179,6 +179,29 @@ void orc_describe(const orc_image* ii, int stable, const orc_surf_cfg* cfg, doub
 	*white = bf.white ? 1 : 0;
 }
 
+
+// ---- small pieces re-expressed for the reference's own unit tests (tests/test_oracle_reference_tests.py) ----
+// SurfDescribeOps.isInside(ii, X, Y, radiusRegions, kernelSize, scale, c, s)   F:alg/feature/describe/SurfDescribeOps.java:120-159
+int orc_surf_is_inside(int width, int height, double X, double Y, int radiusRegions, int kernelSize, double scale, double c, double s) {
+	GrayF32 v(width, height);
+	return surfIsInside(v, X, Y, radiusRegions, kernelSize, scale, c, s) ? 1 : 0;
+}
+// SurfDescribeOps.isInside(width, height, tl_x, tl_y, regionSize, sampleSize)   :183-204
+int orc_surf_is_inside_region(int width, int height, double tl_x, double tl_y, double regionSize, double sampleSize) {
+	return surfIsInsideRegion(width, height, tl_x, tl_y, regionSize, sampleSize) ? 1 : 0;
+}
+// UtilFeature.normalizeL2(TupleDesc_F64)   F:alg/descriptor/UtilFeature.java:101-114
+void orc_normalize_l2(double* v, int n) { normalizeL2(v, n); }
+// org.ddogleg.stats.UtilGaussian.computePDF as restated (published formula; ddogleg is not in the reference tree)
+double orc_compute_pdf(double mean, double sigma, double sample) { return computePDF(mean, sigma, sample); }
+// SparseIntegralGradient_NoBorder_F32.setWidth / isInBounds: the sample box bounds and the in-bounds predicate
+int orc_sparse_gradient_bounds(int width, int height, double kernelWidth, int x, int y, int* box /*x0,y0,x1,y1*/) {
+	GrayF32 v(width, height);
+	SparseIntegralGradient_NoBorder_F32 g; g.input = &v; g.setWidth(kernelWidth);
+	box[0] = g.x0; box[1] = g.y0; box[2] = g.x1; box[3] = g.y1;
+	return g.isInBounds(x, y) ? 1 : 0;
+}
+
 // ---- kernels (for table tests) ----
 int orc_gaussian_width(double sigma, int width, double* out) {
 	Kernel2D_F64 k = gaussianWidth(sigma, width);

@@ -93,6 +93,11 @@ def lib():
             "orc_orientation": (C.c_double, [IM, C.c_int, P(OriCfg), C.c_double, C.c_double, C.c_double]),
             "orc_sparse_gradient": (C.c_int, [IM, C.c_double, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]),
             "orc_describe": (None, [IM, C.c_int, P(SurfCfg), C.c_double, C.c_double, C.c_double, C.c_double, P(C.c_double), P(C.c_uint8), C.c_int]),
+            "orc_surf_is_inside": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]),
+            "orc_surf_is_inside_region": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+            "orc_normalize_l2": (None, [P(C.c_double), C.c_int]),
+            "orc_compute_pdf": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+            "orc_sparse_gradient_bounds": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, P(C.c_int)]),
             "orc_gaussian_width": (C.c_int, [C.c_double, C.c_int, P(C.c_double)]),
             "orc_gaussian2d_f64": (C.c_int, [C.c_double, C.c_int, P(C.c_double)]),
             "orc_gaussian1d_f32": (C.c_int, [C.c_double, C.c_int, P(C.c_float)]),

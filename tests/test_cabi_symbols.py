@@ -71,3 +71,23 @@ def test_shipped_library_has_no_experiment_switches():
     for name in (b"BHIP_FUSED_ABLATE", b"BHIP_FUSED_VARIANT", b"BHIP_DESCRIBE_LDSPAD", b"BHIP_DESCRIBE_STAMPS", b"BHIP_DESCRIBE_NOORDER"):
         assert name not in blob, name
     assert b"BHIP_DETECT_UNFUSED" in blob
+
+
+def test_image_views_are_validated_before_raw_pointers_leave_python():
+    """api.GrayF32 / GrayU8 reject views that do not fit their array (the C side only sees a pointer)."""
+    import numpy as np
+    from boofcv_amd import api
+    data = np.zeros(100, np.float32)
+    api.GrayF32(10, 10, data)
+    for bad in (dict(width=10, height=11), dict(width=10, height=10, startIndex=1), dict(width=10, height=10, stride=11), dict(width=10, height=10, stride=9)):
+        kw = dict(width=10, height=10, startIndex=0, stride=None)
+        kw.update(bad)
+        with pytest.raises(api.IllegalArgumentException):
+            api.GrayF32(kw["width"], kw["height"], data, kw["startIndex"], kw["stride"])
+    img = api.GrayF32(10, 10, data)
+    img.subimage(2, 3, 10, 10)
+    for box in ((2, 3, 11, 10), (-1, 0, 5, 5), (6, 0, 5, 5)):
+        with pytest.raises(api.IllegalArgumentException):
+            img.subimage(*box)
+    with pytest.raises(api.IllegalArgumentException):
+        api.GrayU8(4, 4, np.zeros(15, np.uint8))
