@@ -28,6 +28,7 @@
 //   * the 81-term sub-region sums keep the reference's sequential fp64 order per output but fetch a whole row of samples and
 //     weights per wait.
 #include "common.h"
+#include <algorithm>
 
 struct DescParams {
 	ImgView ii;
@@ -59,6 +60,7 @@ struct DescParams {
 
 #define ORI_EPL_MAX 8     // orientation samples per lane (n <= 512, i.e. radius <= 10)
 #define DESC_ROW_MAX 16   // samples per sub-region row (widthSubRegion + 2*overLap)
+#define DESC_BATCH 3      // descriptor samples per lane whose 12 taps each are in flight together
 
 // ---- sparse gradient (SparseIntegralGradient_NoBorder_F32) ----
 __device__ __forceinline__ int gradRadius(double width) {
@@ -80,29 +82,43 @@ __device__ __forceinline__ GradGeom makeGeom(int r, int stride, int W, int H) {
 	return g;
 }
 // T = float (GrayF32 integral image: SparseIntegralGradient_NoBorder_F32) or int (GrayS32, the integral image of a GrayU8 frame:
-// SparseIntegralGradient_NoBorder_I32.java:46-76 -- integer box differences, handed on as exact values)
+// SparseIntegralGradient_NoBorder_I32.java:46-76 -- integer box differences, handed on as exact values).
+// A sample is taken in two steps so that a whole batch of samples has its 12 x batch loads in flight before the first one is waited for:
+// gradFetch issues the taps with NO control flow (a sample that is switched off, or whose kernel leaves the image, reads the safe position
+// instead; an image smaller than the kernel collapses every offset to 0), gradFinish combines them in the reference's order.
 template <class T>
-__device__ __forceinline__ void gradSample(const T* __restrict__ d, const GradGeom& G, int x, int y, T& gx, T& gy) {
+struct GradTaps {
+	T p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11;
+	bool inb;
+};
+template <class T>
+__device__ __forceinline__ void gradFetch(const T* __restrict__ d, const GradGeom& G, int x, int y, bool on, GradTaps<T>& t) {
 	const int r = G.r;
-	const bool inb = x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < G.W && y + r < G.H;
+	const bool inb = on && G.anyInside && x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < G.W && y + r < G.H;
 	const int xs = inb ? x : G.safe, ys = inb ? y : G.safe;
+	// wave-uniform strides; all zero when the image is smaller than the kernel (nothing may be read beyond element 0 then)
+	const unsigned int st = G.anyInside ? (unsigned)G.stride : 0u, rr = G.anyInside ? (unsigned)r : 0u, w = G.anyInside ? (unsigned)G.w : 0u;
+	const unsigned int one = G.anyInside ? 1u : 0u;
 	// 32-bit element offsets from the (wave-uniform) image base: one integral image is far below 2^31 floats (W, H < 32768 is enforced
-	// by the detector, and the host rejects larger images for describe), and a uniform base + 32-bit lane offset is the cheap address form
-	const int s1 = (ys - r - 1) * G.stride + (xs - r - 1);
-	const int s2 = s1 + r * G.stride;
-	const int s3 = s2 + G.stride;
-	const int s4 = s3 + r * G.stride;
-	const int w = G.w;
-	const T p0 = d[s1], p1 = d[s1 + r], p2 = d[s1 + r + 1], p3 = d[s1 + w];
-	const T p11 = d[s2], p4 = d[s2 + w];
-	const T p10 = d[s3], p5 = d[s3 + w];
-	const T p9 = d[s4], p8 = d[s4 + r], p7 = d[s4 + r + 1], p6 = d[s4 + w];
-	const T left = p8 - p9 - p1 + p0;
-	const T right = p6 - p7 - p3 + p2;
-	const T top = p4 - p11 - p3 + p0;
-	const T bottom = p6 - p9 - p5 + p10;
-	gx = inb ? right - left : T(0);
-	gy = inb ? bottom - top : T(0);
+	// by the detector, and the host rejects larger images for describe); unsigned, as the safe coordinates are never negative
+	const unsigned int s1 = (unsigned)(ys - r - 1) * st + (unsigned)(xs - r - 1) * one;
+	const unsigned int s2 = s1 + rr * st;
+	const unsigned int s3 = s2 + st;
+	const unsigned int s4 = s3 + rr * st;
+	t.p0 = d[s1]; t.p1 = d[s1 + rr]; t.p2 = d[s1 + rr + one]; t.p3 = d[s1 + w];
+	t.p11 = d[s2]; t.p4 = d[s2 + w];
+	t.p10 = d[s3]; t.p5 = d[s3 + w];
+	t.p9 = d[s4]; t.p8 = d[s4 + rr]; t.p7 = d[s4 + rr + one]; t.p6 = d[s4 + w];
+	t.inb = inb;
+}
+template <class T>
+__device__ __forceinline__ void gradFinish(const GradTaps<T>& t, T& gx, T& gy) {
+	const T left = t.p8 - t.p9 - t.p1 + t.p0;
+	const T right = t.p6 - t.p7 - t.p3 + t.p2;
+	const T top = t.p4 - t.p11 - t.p3 + t.p0;
+	const T bottom = t.p6 - t.p9 - t.p5 + t.p10;
+	gx = t.inb ? right - left : T(0);
+	gy = t.inb ? bottom - top : T(0);
 }
 
 // georegression UtilAngle.dist: circular distance in [0,pi]
@@ -353,6 +369,121 @@ __device__ __forceinline__ bool sortSamplesFast32(const T* gX, const T* gY, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Counting sort of the (angle, index) pairs -- the normal path.  bin(angle) is a monotone function of the angle (float conversion, add,
+// multiply by a positive constant, truncation: each monotone), so ordering by bin and then exactly by (fp64 angle, index) inside a bin IS
+// the (angle, index) order of the merge sorts above.  ORI_BINS bins of 2*pi/1024 rad hold 0.3 samples on average: a lane counts its
+// samples into packed 16-bit LDS counters, one wave-wide exclusive scan turns the counts into bin offsets, every sample ranks itself
+// against the other members of its bin, and is scattered straight from registers to its sorted slot (the samples never visit LDS
+// unsorted).  The offsets stay in LDS: the window search below reads "how many samples lie below angle x" from them instead of
+// binary-searching the sorted angles.  A bin with more than ORI_BIN_MAX members (a run of equal angles: samples outside the image have a
+// zero gradient, angle 0) makes the function return false; the caller then takes the merge-sort path.
+#define ORI_BINS 1024
+#define ORI_BIN_MAX 8
+__device__ __forceinline__ int angleBin(double a) {
+	const float f = ((float)a + 3.14159274f) * ((float)ORI_BINS / 6.28318548f);
+	return min(max((int)f, 0), ORI_BINS - 1);
+}
+__device__ __forceinline__ int binOffset(const unsigned int* bins, int b) { return (int)((bins[b >> 1] >> ((b & 1) * 16)) & 0xffffu); }
+
+template <int EPLT>
+__device__ __forceinline__ bool countingSortScatter(const double (&a)[EPLT], const double (&dx)[EPLT], const double (&dy)[EPLT], int n, int lane,
+													 unsigned int* bins, double* tmpA, unsigned short* tmpI, double* dX, double* dY, double* sA) {
+	static_assert(ORI_BINS == 1024, "two 16-byte stores per lane clear the counters");
+	{
+		const uint4 z = make_uint4(0, 0, 0, 0);
+		reinterpret_cast<uint4*>(bins)[2 * lane] = z;
+		reinterpret_cast<uint4*>(bins)[2 * lane + 1] = z;
+	}
+	waveSync();
+	int bin[EPLT], r[EPLT];
+#pragma unroll
+	for (int e = 0; e < EPLT; e++) {
+		bin[e] = angleBin(a[e]);
+		r[e] = 0;
+		if (lane + 64 * e < n) {
+			const int sh = (bin[e] & 1) * 16;
+			const unsigned int old = atomicAdd(&bins[bin[e] >> 1], 1u << sh);
+			r[e] = (int)((old >> sh) & 0xffffu);
+		}
+	}
+	waveSync();
+	int cnt[EPLT];
+	int mx = 0;
+#pragma unroll
+	for (int e = 0; e < EPLT; e++) {
+		cnt[e] = lane + 64 * e < n ? binOffset(bins, bin[e]) : 0;
+		mx = max(mx, cnt[e]);
+	}
+#pragma unroll
+	for (int o = 32; o >= 1; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+	if (mx > ORI_BIN_MAX) return false;   // wave-uniform
+	waveSync();   // every count has been read before the counters turn into offsets
+	{
+		// exclusive scan over the 1024 counters: 16 per lane (8 words), then across the lanes
+		const uint4 w0 = reinterpret_cast<const uint4*>(bins)[2 * lane], w1 = reinterpret_cast<const uint4*>(bins)[2 * lane + 1];
+		const unsigned int w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+		unsigned int pre[16];
+		unsigned int run = 0;
+#pragma unroll
+		for (int i = 0; i < 8; i++) {
+			pre[2 * i] = run; run += w[i] & 0xffffu;
+			pre[2 * i + 1] = run; run += w[i] >> 16;
+		}
+		unsigned int sc = run;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const unsigned int t = __shfl_up(sc, o, 64);
+			if (lane >= o) sc += t;
+		}
+		const unsigned int base = sc - run;
+		unsigned int ow[8];
+#pragma unroll
+		for (int i = 0; i < 8; i++) ow[i] = (base + pre[2 * i]) | ((base + pre[2 * i + 1]) << 16);
+		reinterpret_cast<uint4*>(bins)[2 * lane] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+		reinterpret_cast<uint4*>(bins)[2 * lane + 1] = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+	}
+	waveSync();
+	int off[EPLT];
+#pragma unroll
+	for (int e = 0; e < EPLT; e++) {
+		off[e] = 0;
+		if (lane + 64 * e < n) {
+			off[e] = binOffset(bins, bin[e]);
+			tmpA[off[e] + r[e]] = a[e];
+			tmpI[off[e] + r[e]] = (unsigned short)(lane + 64 * e);
+		}
+	}
+	waveSync();
+	int rank[EPLT];
+#pragma unroll
+	for (int e = 0; e < EPLT; e++) rank[e] = 0;
+	if (mx > 1) {
+		for (int k = 0; k < mx; k++) {
+			double ak[EPLT];
+			int ik[EPLT];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				const bool on = k < cnt[e];
+				ak[e] = on ? tmpA[off[e] + k] : 0.0;
+				ik[e] = on ? (int)tmpI[off[e] + k] : 0;
+			}
+#pragma unroll
+			for (int e = 0; e < EPLT; e++)
+				if (k < cnt[e] && (ak[e] < a[e] || (ak[e] == a[e] && ik[e] < lane + 64 * e))) rank[e]++;
+		}
+	}
+	waveSync();   // tmpA / tmpI are dead: the sorted arrays may overwrite them
+#pragma unroll
+	for (int e = 0; e < EPLT; e++)
+		if (lane + 64 * e < n) {
+			const int f = off[e] + rank[e];
+			dX[f] = dx[e]; dY[f] = dy[e]; sA[f] = a[e];
+		}
+	waveSync();
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Sliding-window orientation, wave-parallel form of ImplOrientationSlidingWindowIntegral.estimateAngle (:139-188).
 //
 // The reference sorts the n angles and sweeps two pointers: for every start a the window grows while
@@ -368,8 +499,8 @@ __device__ __forceinline__ bool sortSamplesFast32(const T* gX, const T* gY, cons
 // The full-circle regime (some window wraps all the way round: ramps, flat patches) is detected and left to the serial code.
 // Returns false when the caller must run the serial sweep (the arrays are then still the sorted samples).
 template <int EPLT>
-__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, const float* sF, int* Esched, int n, double window, int lane,
-												   double& bestX, double& bestY, unsigned long long* st /*diagnostic stamps or nullptr*/) {
+__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, const float* sF, const unsigned int* bins, int* Esched, int n,
+												   double window, int lane, double& bestX, double& bestY, unsigned long long* st /*diagnostic stamps or nullptr*/) {
 #define WSTAMP(i) do { if (st && lane == 0) st[i] = __builtin_readcyclecounter(); } while (0)
 	const int EPL = (n + 63) >> 6;   // <= EPLT
 	const int p0 = lane * EPL;
@@ -387,6 +518,23 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 		if (!(winLo > 0.0f)) return false;
 		float fa[EPLT];
 		int lo[EPLT], hi[EPLT];
+		if (bins) {
+			// coarse part from the counting sort's offsets: every sample in a bin below bin(T), T = angle + window - 1e-9, has an angle below
+			// T (the bin function is monotone), i.e. is inside the window by a margin far above fp64 rounding.  offsets[bin(T)] is the number
+			// of such samples; past +pi the window continues from -pi.
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				lo[e] = 0;
+				if (e < cnt) {
+					const int a = p0 + e;
+					const double T = sA[a] + (window - 1.0e-9);
+					const bool wrap = T >= M_PI;
+					const int below = binOffset(bins, angleBin(wrap ? T - 2.0 * M_PI : T));
+					const int c0 = (wrap ? n + below : below) - (a + 1);
+					lo[e] = min(max(c0, 0), n - 1);
+				}
+			}
+		} else {
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
 			fa[e] = e < cnt ? sF[p0 + e] : 0.0f;
@@ -412,32 +560,58 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 				}
 			}
 		}
+		}
 		double ta[EPLT], nxt[EPLT];
+		int cc[EPLT];
+		bool act[EPLT];
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
 			ta[e] = e < cnt ? sA[p0 + e] : 0.0;
+			cc[e] = lo[e];
+			act[e] = e < cnt && lo[e] < n - 1;
 			const int kabs = p0 + e + lo[e] + 1;
 			const int k = kabs >= n ? kabs - n : kabs;
-			nxt[e] = (e < cnt && lo[e] < n - 1) ? sA[k] : 0.0;
+			nxt[e] = act[e] ? sA[k] : 0.0;
+			if (e < cnt && !act[e]) abnormal = true;   // the coarse count alone already spans the whole list: full-circle regime
+		}
+		// exact continuation, all of a lane's starts in lock step (their LDS reads overlap): the reference's own test walks on from the
+		// coarse count -- normally it fails at once; a handful of steps at most unless many samples sit within 1e-9 of the window edge
+		for (int guard = 0; guard < 18; guard++) {
+			bool any = false;
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				if (act[e]) {
+					const int kabs = p0 + e + cc[e] + 1;
+					const double fo = (nxt[e] - ta[e]) + (kabs >= n ? 2.0 * M_PI : 0.0);
+					const bool inside = angleDist(ta[e], nxt[e]) <= window;
+					if (!(fo < M_PI && inside)) {
+						// UtilAngle.dist is symmetric: a successor that lies within the window BEHIND the start (the sweep has come round past
+						// +-pi, or past the end of the sorted list) still passes the reference's test and the reference keeps adding -- the window
+						// then runs on round the circle.  Not a leading-side window: leave it to the serial sweep.
+						if (inside) abnormal = true;
+						act[e] = false;
+					} else {
+						cc[e]++;
+						if (cc[e] >= n - 1) { abnormal = true; act[e] = false; }
+						else if (guard == 17) { abnormal = true; act[e] = false; }   // a long run of samples at the window edge
+					}
+				}
+			}
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				if (act[e]) {
+					const int k2abs = p0 + e + cc[e] + 1;
+					nxt[e] = sA[k2abs >= n ? k2abs - n : k2abs];
+					any = true;
+				}
+			}
+			if (!__any(any)) break;
 		}
 #pragma unroll
 		for (int e = 0; e < EPLT; e++) {
 			valE[e] = 0;
 			if (e < cnt) {
-				int c = lo[e];
-				// exact continuation; a handful of steps at most unless many samples sit within 1e-5 of the window edge
-				int guard = 0;
-				while (c < n - 1) {
-					const int kabs = p0 + e + c + 1;
-					const double fo = (nxt[e] - ta[e]) + (kabs >= n ? 2.0 * M_PI : 0.0);
-					if (!(fo < M_PI && angleDist(ta[e], nxt[e]) <= window)) break;
-					c++;
-					if (++guard > 16) { abnormal = true; break; }
-					const int k2abs = p0 + e + c + 1;
-					nxt[e] = c < n - 1 ? sA[k2abs >= n ? k2abs - n : k2abs] : 0.0;
-				}
-				if (c >= n - 1) abnormal = true;
-				valE[e] = p0 + e + c + 1;
+				valE[e] = p0 + e + cc[e] + 1;
 				runMax = max(runMax, valE[e]);
 			}
 		}
@@ -577,10 +751,16 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 
 // EPLT = orientation samples per lane = ceil(n / 64), TWT = samples per sub-region row: compile-time for the common configurations so
 // the unrolled batches carry no dead slots (the kernel is issue bound); <8,16> is the generic instantiation.
-template <bool STAMP, int EPLT, int TWT, class TAP>
+// CFG: 0 = every size comes from the tables at run time; 1 = FactoryDetectDescribe.surfStable defaults (4x4 grid of 5-sample sub-regions,
+// overlap 2, 17x17 sliding-window orientation grid); 2 = surfFast defaults (4x4 grid of 5, no overlap, 13x13 average orientation).  With
+// the sizes known the index arithmetic (sample -> row/column, feature -> sub-region) folds to shifts and multiplies.
+template <bool STAMP, int EPLT, int TWT, class TAP, int CFG = 0>
 __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ldsAll[];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	// the wave index is uniform by construction; telling the compiler so keeps everything derived from the key point (image, scale, kernel
+	// radius, tap strides) in scalar registers and the gathers in base + 32-bit-offset form
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int lane = threadIdx.x & 63;
 	// XCD-aware order (blocks are dealt round-robin over the 8 XCDs): block b takes key-point group (b % 8) * chunk + b / 8, so each
 	// XCD works through its own contiguous run of key points -- one or two images at a time in its L2 instead of the whole batch
 	const long long nblk = (P.total + 3) >> 2;
@@ -625,7 +805,8 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		double tl_y = kp.y - T.oriRadius * period;
 		tl_x += 0.5;
 		tl_y += 0.5;
-		const int sw = T.oriWidth, n = sw * sw;
+		const bool oriSliding = CFG == 1 ? true : CFG == 2 ? false : (T.oriStable != 0);
+		const int sw = CFG == 1 ? 17 : CFG == 2 ? 13 : T.oriWidth, n = sw * sw;
 		// sort-phase layout (see sortSamplesByAngle); the average variant only stages its addends as dX, dY
 		TAP* gX = (TAP*)lds;
 		TAP* gY = gX + n;
@@ -633,51 +814,53 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		double* keyB = (double*)(lds + (size_t)16 * n);
 		double* dX = (double*)lds;
 		double* dY = dX + n;
+		// all of this lane's samples: taps first (independent loads in flight together), then the fp64 tail.  The sliding-window variant
+		// keeps its samples (weighted gradient, angle) in registers: the counting sort scatters them straight to their sorted slots.
+		TAP gx[EPLT], gy[EPLT];
+		double dxr[EPLT], dyr[EPLT], ar[EPLT];
 		{
-			// all of this lane's samples: taps first (independent loads in flight together), then the fp64 tail
-			TAP gx[EPLT], gy[EPLT];
+			GradTaps<TAP> tp[EPLT];
 #pragma unroll
 			for (int e = 0; e < EPLT; e++) {
 				const int idx = lane + 64 * e;
-				gx[e] = TAP(0); gy[e] = TAP(0);
-				if (idx < n && G.anyInside) {
-					const int sy = idx / sw, sx = idx - sy * sw;
-					const int xx = (int)(tl_x + sx * period);
-					const int yy = (int)(tl_y + sy * period);
-					gradSample<TAP>(d, G, xx, yy, gx[e], gy[e]);
-				}
+				const int sy = idx / sw, sx = idx - sy * sw;
+				const int xx = (int)(tl_x + sx * period);
+				const int yy = (int)(tl_y + sy * period);
+				gradFetch<TAP>(d, G, xx, yy, idx < n, tp[e]);
 			}
 #pragma unroll
-			for (int e = 0; e < EPLT; e++) {
-				const int idx = lane + 64 * e;
-				if (idx < n) {
-					double dx = (double)gx[e], dy = (double)gy[e];
-					if (T.oriStable) {
-						if (T.oriHasWeights) {
-							const double w = T.oriWeights[idx];
-							dx *= w;
-							dy *= w;
-						}
-						gX[idx] = gx[e];
-						gY[idx] = gy[e];
-						ang[idx] = atan2(dy, dx);
+			for (int e = 0; e < EPLT; e++) gradFinish<TAP>(tp[e], gx[e], gy[e]);
+		}
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) {
+			const int idx = lane + 64 * e;
+			dxr[e] = 0.0; dyr[e] = 0.0; ar[e] = 0.0;
+			if (idx < n) {
+				double dx = (double)gx[e], dy = (double)gy[e];
+				if (oriSliding) {
+					if (T.oriHasWeights) {
+						const double w = T.oriWeights[idx];
+						dx *= w;
+						dy *= w;
+					}
+					dxr[e] = dx; dyr[e] = dy;
+					ar[e] = atan2(dy, dx);
+				} else {
+					// average variant accumulates w*gx (or gx) in row-major order; stage the addends
+					if (T.oriHasWeights) {
+						const double w = T.oriWeights[idx];
+						dX[idx] = w * dx;
+						dY[idx] = w * dy;
 					} else {
-						// average variant accumulates w*gx (or gx) in row-major order; stage the addends
-						if (T.oriHasWeights) {
-							const double w = T.oriWeights[idx];
-							dX[idx] = w * dx;
-							dY[idx] = w * dy;
-						} else {
-							dX[idx] = dx;
-							dY[idx] = dy;
-						}
+						dX[idx] = dx;
+						dY[idx] = dy;
 					}
 				}
 			}
 		}
 		waveSync();
 		DSTAMP(1);
-		if (T.oriStable) {
+		if (oriSliding) {
 			unsigned short* idxA = (unsigned short*)(lds + (size_t)24 * n);
 			unsigned short* idxB = idxA + n;
 			double bestX = 0, bestY = 0;
@@ -685,12 +868,23 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			// n <= 64 * EPLT is enforced on the host
 			const OriSortOut so{dX, dY, dY + n, (float*)(lds + (size_t)28 * n)};
 			const double* wts = T.oriHasWeights ? T.oriWeights : nullptr;
-			bool sorted = false;
-			if (!P.sort64) sorted = sortSamplesFast32<EPLT, TAP>(gX, gY, ang, (unsigned int*)keyB, (unsigned int*)keyB + n, idxA, idxB, wts, so, n, lane);
-			if (!sorted) sortSamplesByAngle<EPLT, TAP>(gX, gY, ang, keyB, idxA, idxB, wts, so, n, lane);
+			unsigned int* bins = (unsigned int*)(lds + (((size_t)28 * n + 15) & ~(size_t)15));
+			const bool counted = !P.sort64 && countingSortScatter<EPLT>(ar, dxr, dyr, n, lane, bins, (double*)lds, (unsigned short*)(lds + (size_t)8 * n), dX, dY, dY + n);
+			if (!counted) {
+				// merge-sort path (a crowded bin, or the BHIP_DESCRIBE_SORT64 cross-check): the unsorted samples go to LDS first
+#pragma unroll
+				for (int e = 0; e < EPLT; e++) {
+					const int idx = lane + 64 * e;
+					if (idx < n) { gX[idx] = gx[e]; gY[idx] = gy[e]; ang[idx] = ar[e]; }
+				}
+				waveSync();
+				bool sorted = false;
+				if (!P.sort64) sorted = sortSamplesFast32<EPLT, TAP>(gX, gY, ang, (unsigned int*)keyB, (unsigned int*)keyB + n, idxA, idxB, wts, so, n, lane);
+				if (!sorted) sortSamplesByAngle<EPLT, TAP>(gX, gY, ang, keyB, idxA, idxB, wts, so, n, lane);
+			}
 			ang = so.sA;   // sorted angles; dX, dY hold the sorted samples
 			DSTAMP(2);
-			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
+			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, counted ? bins : nullptr, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
 			if (needSerial) {
 				// estimateAngle() exactly as written in the reference, on the arrays already in sorted order (order[k] == k).
 				// Reached for the full-circle regime (all gradients within one window of each other: ramps, flat patches).
@@ -743,9 +937,11 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const double c = cos(angle), s = sin(angle);
 	const double scale = kp.scale;
 	const GradGeom G = makeGeom(gradRadius(T.widthSample * scale), stride, W, H);
-	const int regionSize = T.widthLargeGrid * T.widthSubRegion;
+	const int widthLargeGrid = CFG ? 4 : T.widthLargeGrid, widthSubRegion = CFG ? 5 : T.widthSubRegion;
+	const bool stableDesc = CFG == 1 ? true : CFG == 2 ? false : (T.stable != 0);
+	const int regionSize = widthLargeGrid * widthSubRegion;
 	const int regionR = regionSize / 2;
-	const int overLap = T.stable ? T.overLap : 0;
+	const int overLap = CFG == 1 ? 2 : CFG == 2 ? 0 : (T.stable ? T.overLap : 0);
 	const int gridW = regionSize + 2 * overLap;
 	const int nsamp = gridW * gridW;
 	// the samples are widened to double once, when they are stored (each is read by up to 16 output lanes in the sums below)
@@ -772,8 +968,9 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		const int cy = (corner == 0 || corner == 2) ? by1 : by0;
 		if (cx >= 0 && cy >= 0) lapTap = d[(long long)cy * stride + cx];
 	}
-	const int dof = T.dof;
+	const int dof = CFG ? 64 : T.dof;
 	const int nb = P.nBands > 0 ? P.nBands : 1;
+#pragma unroll 1
 	for (int band = 0; band < nb; band++) {
 	const TAP* __restrict__ db = P.nBands > 0 ? (const TAP*)P.bandData + (long long)img * P.bandImageStride + (long long)band * P.bandStride : d;
 	if (band > 0) waveSync();   // the previous band's sums have read sX, sY
@@ -784,43 +981,76 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		const int blocksPerSide = (gridW + 7) >> 3;
 		const int nblocks = blocksPerSide * blocksPerSide;
 		const int ly = lane >> 3, lx = lane & 7;
-		for (int b0 = 0; b0 < nblocks; b0 += 3) {
-			TAP gx[3], gy[3];
-			int at[3];
+#pragma unroll 1
+		for (int b0 = 0; b0 < nblocks; b0 += DESC_BATCH) {
+			GradTaps<TAP> tp[DESC_BATCH];
+			int at[DESC_BATCH];
 #pragma unroll
-			for (int u = 0; u < 3; u++) {
+			for (int u = 0; u < DESC_BATCH; u++) {
 				const int b = b0 + u;
 				const int by = b / blocksPerSide, bx = b - by * blocksPerSide;
 				const int iy = 8 * by + ly, ix = 8 * bx + lx;
 				const bool on = b < nblocks && iy < gridW && ix < gridW;
 				at[u] = on ? iy * gridW + ix : -1;
-				gx[u] = TAP(0); gy[u] = TAP(0);
-				if (on && G.anyInside) {
-					const int rY = iy - regionR - overLap, rX = ix - regionR - overLap;
-					const double regionY = rY * scale;
-					const double regionX = rX * scale;
-					const int pixelX = (int)(c_x + c * regionX - s * regionY);
-					const int pixelY = (int)(c_y + s * regionX + c * regionY);
-					gradSample<TAP>(db, G, pixelX, pixelY, gx[u], gy[u]);
-				}
+				const int rY = iy - regionR - overLap, rX = ix - regionR - overLap;
+				const double regionY = rY * scale;
+				const double regionX = rX * scale;
+				const int pixelX = (int)(c_x + c * regionX - s * regionY);
+				const int pixelY = (int)(c_y + s * regionX + c * regionY);
+				gradFetch<TAP>(db, G, pixelX, pixelY, on, tp[u]);
 			}
 #pragma unroll
-			for (int u = 0; u < 3; u++)
-				if (at[u] >= 0) { sX[at[u]] = (double)gx[u]; sY[at[u]] = (double)gy[u]; }
+			for (int u = 0; u < DESC_BATCH; u++) {
+				TAP gx, gy;
+				gradFinish<TAP>(tp[u], gx, gy);
+				if (at[u] >= 0) { sX[at[u]] = (double)gx; sY[at[u]] = (double)gy; }
+			}
 		}
 	}
 	waveSync();
 	DSTAMP(4);
-	const int T_w = T.widthSubRegion + 2 * overLap;  // samples per sub-region side (<= TWT, enforced on the host)
+	const int T_w = widthSubRegion + 2 * overLap;  // samples per sub-region side (<= TWT, enforced on the host)
+	if (widthLargeGrid == 4) {
+		// 16 sub-regions x 4 lanes: lane (sub, q) takes every fourth sample of its sub-region (t = q, q+4, ...), builds the rotated gradient
+		// once and adds it into all four sums; the four partial sums meet in two butterfly steps.  A third of the instructions of one lane
+		// per output (which evaluates w*gx, w*gy and the rotation four times over).  The order of the additions differs from the reference's
+		// single running sum per output: a few ulp of the sum, ~1e-16 on the unit descriptor, against the 1e-5 bar.
+		const int sub = lane >> 2, q = lane & 3;
+		const int suby = sub >> 2, subx = sub & 3;
+		const int rY = -regionR + suby * widthSubRegion, rX = -regionR + subx * widthSubRegion;
+		const int base = (rY + regionR) * gridW + rX + regionR;
+		const int nT = T_w * T_w;
+		const double ms = -s;
+		double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 3
+		for (int t = q; t < nT; t += 4) {
+			const int i = t / T_w, j = t - i * T_w;
+			const double vx = sX[base + i * gridW + j], vy = sY[base + i * gridW + j];
+			const double w = stableDesc ? T.weightSub[t] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
+			const double dx = w * vx, dy = w * vy;
+			const double pdx = c * dx + s * dy;
+			const double pdy = ms * dx + c * dy;
+			a0 += pdx; a1 += fabs(pdx); a2 += pdy; a3 += fabs(pdy);
+		}
+#pragma unroll
+		for (int o = 1; o <= 2; o <<= 1) {
+			a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); a3 += __shfl_xor(a3, o, 64);
+		}
+		double sum = q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3;
+		if (stableDesc) sum = T.weightGrid[sub] * sum;
+		feat[band * dof + lane] = sum;
+	} else
+#pragma unroll 1
 	for (int f = lane; f < dof; f += 64) {
 		const int sub = f >> 2, comp = f & 3;
-		const int suby = sub / T.widthLargeGrid, subx = sub - suby * T.widthLargeGrid;
-		const int rY = -regionR + suby * T.widthSubRegion, rX = -regionR + subx * T.widthSubRegion;
+		const int suby = sub / widthLargeGrid, subx = sub - suby * widthLargeGrid;
+		const int rY = -regionR + suby * widthSubRegion, rX = -regionR + subx * widthSubRegion;
 		// this lane's component as one linear form: pdx = c*dx + s*dy (comp 0,1), pdy = -s*dx + c*dy (comp 2,3); (-s)*dx is the exact
 		// negation of s*dx, so the sum below is bit-identical to the reference's expression.  |.| for the odd components is a sign mask.
 		const double cA = comp < 2 ? c : -s, cB = comp < 2 ? s : c;
 		const unsigned long long absMask = (comp & 1) ? 0x7fffffffffffffffull : 0xffffffffffffffffull;
 		double sum = 0;
+#pragma unroll 1
 		for (int i = 0; i < T_w; i++) {
 			const int index = (rY + regionR + i) * gridW + rX + regionR;
 			// one wait per row: the row's samples and weights are fetched together, then summed in the reference's order
@@ -831,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				const bool on = j < T_w;
 				vx[j] = on ? sX[index + j] : 0.0;
 				vy[j] = on ? sY[index + j] : 0.0;
-				w[j] = !on ? 0.0 : T.stable ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
+				w[j] = !on ? 0.0 : stableDesc ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
 			}
 #pragma unroll
 			for (int j = 0; j < TWT; j++) {
@@ -843,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				}
 			}
 		}
-		if (T.stable) sum = T.weightGrid[sub] * sum;
+		if (stableDesc) sum = T.weightGrid[sub] * sum;
 		feat[band * dof + f] = sum;
 	}
 	}   // bands
@@ -887,7 +1117,9 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 
 int bhip_describe_lds_bytes(const SurfTables& t, int nBands) {
 	const int n = t.oriWidth * t.oriWidth;
-	const int ori = n * 32 + 16;  // see sortSamplesByAngle: 28n while sorting; dX dY sA Esched + the fp32 copy of the sorted angles afterwards
+	// merge-sort path: 28n while sorting, then dX dY sA Esched + the fp32 copy of the sorted angles (32n); counting-sort path: dX dY sA Esched
+	// (28n) + the 1024 packed bin counters / offsets (2 KB, 16-byte aligned)
+	const int ori = std::max(n * 32 + 16, ((28 * n + 15) & ~15) + 2048);
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
@@ -931,7 +1163,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 			{
 				const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
 				const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
-				if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<true, 5, 9, float>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+				if (epl == 5 && tw == 9 && t.stable && t.overLap == 2 && t.widthLargeGrid == 4 && t.oriStable) hipLaunchKernelGGL((k_describe<true, 5, 9, float, 1>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 				else hipLaunchKernelGGL((k_describe<true, 8, 16, float>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 			}
 			std::vector<unsigned long long> h((size_t)total * 16);
@@ -973,20 +1205,21 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 #ifdef BHIP_EXPERIMENTS
 		{ const char* e = getenv("BHIP_DESCRIBE_LDSPAD"); if (e) ldsBytes += (size_t)atoi(e); }   // occupancy experiments only
 #endif
+		// default configurations get compile-time sizes (CFG 1 / 2); anything else runs the generic instantiations
+		const bool defGrid = t.widthLargeGrid == 4 && t.widthSubRegion == 5 && t.dof == 64;
+		const bool cfgStable = defGrid && t.stable && t.overLap == 2 && t.oriStable && t.oriWidth == 17;
+		const bool cfgFast = defGrid && !t.stable && !t.oriStable && t.oriWidth == 13;
+		const bool ints = planar && planar->intTaps;   // GrayS32 integral image(s)
+		const void* fn;
+		if (cfgStable) fn = ints ? (const void*)k_describe<false, 5, 9, int, 1> : (const void*)k_describe<false, 5, 9, float, 1>;
+		else if (cfgFast) fn = ints ? (const void*)k_describe<false, 3, 5, int, 2> : (const void*)k_describe<false, 3, 5, float, 2>;
+		else if (epl == 5 && tw == 9) fn = ints ? (const void*)k_describe<false, 5, 9, int> : (const void*)k_describe<false, 5, 9, float>;
+		else if (epl == 3 && tw == 5) fn = ints ? (const void*)k_describe<false, 3, 5, int> : (const void*)k_describe<false, 3, 5, float>;
+		else fn = ints ? (const void*)k_describe<false, 8, 16, int> : (const void*)k_describe<false, 8, 16, float>;
 		// colour SURF with many bands / large sample grids need more than the default 64 KB of dynamic LDS
-		if (ldsBytes > 65536) {
-			const void* fn = nullptr;
-			if (planar && planar->intTaps) fn = (epl == 5 && tw == 9) ? (const void*)k_describe<false, 5, 9, int> : (epl == 3 && tw == 5) ? (const void*)k_describe<false, 3, 5, int> : (const void*)k_describe<false, 8, 16, int>;
-			else fn = (epl == 5 && tw == 9) ? (const void*)k_describe<false, 5, 9, float> : (epl == 3 && tw == 5) ? (const void*)k_describe<false, 3, 5, float> : (const void*)k_describe<false, 8, 16, float>;
-			BHIP_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-		}
-		if (planar && planar->intTaps) {   // GrayS32 integral image(s)
-			if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9, int>), grid, block, ldsBytes, ctx->stream, P);
-			else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5, int>), grid, block, ldsBytes, ctx->stream, P);
-			else hipLaunchKernelGGL((k_describe<false, 8, 16, int>), grid, block, ldsBytes, ctx->stream, P);
-		} else if (epl == 5 && tw == 9) hipLaunchKernelGGL((k_describe<false, 5, 9, float>), grid, block, ldsBytes, ctx->stream, P);        // surfStable defaults
-		else if (epl == 3 && tw == 5) hipLaunchKernelGGL((k_describe<false, 3, 5, float>), grid, block, ldsBytes, ctx->stream, P);   // surfFast defaults
-		else hipLaunchKernelGGL((k_describe<false, 8, 16, float>), grid, block, ldsBytes, ctx->stream, P);
+		if (ldsBytes > 65536) BHIP_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+		void* args[] = {(void*)&P};
+		BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, args, ldsBytes, ctx->stream));
 	}
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(FusedParams P) {
 // shrinks to one base.  Same arithmetic, same decisions as k_detect_fused.
 template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
 struct FixedGeo {
-	static constexpr int TX = ITWT - 2 * R, TY = TYT, ITW = ITWT, ITH = TYT + 2 * R, ITp = ITWT + 1;
+	static constexpr int TX = ITWT - 2 * R, TY = TYT, ITW = ITWT, ITH = TYT + 2 * R, ITp = ITWT + 1, HALO = R;
 	static constexpr int sizeMax = SIZE0 + (NL - 1) * STEPSZ;
 	static constexpr int rFmax = sizeMax / 2;
 	static constexpr int IW = (TX - 1 + 2 * R) * SKIP + 2 * rFmax + 2, IH = (TY - 1 + 2 * R) * SKIP + 2 * rFmax + 2;
@@ -258,7 +258,10 @@ struct FixedGeo {
 	// lanes' consecutive output pixels (columns xx = x*SKIP apart) then reads consecutive LDS words -- no bank conflicts for SKIP > 1.
 	static constexpr int IWp = ((IW + SKIP - 1) / SKIP) | 1;      // pitch of one plane row
 	static constexpr int plane = IH * IWp;
-	static constexpr int ldsFloats = SKIP * plane + NL * ITH * ITp;
+	// LDS: the patch, the two dense mid levels (1 and 2 of the four), survivor list + their nine sparse outer-level values
+	static constexpr int SURV = 2 * ((TX + R) / (R + 1)) * ((TY + R) / (R + 1));   // strict (2R+1)^2 maxima of two mid levels: one per (R+1)^2 block at most
+	static constexpr int CHUNK = 64;   // survivors whose nine outer-level values are held at a time
+	static constexpr int ldsFloats = SKIP * plane + 2 * ITH * ITp + SURV + CHUNK * 9 + 4;
 	static constexpr int K0 = rFmax + 1;                          // column of (xx) inside the patch, minus SKIP*(x - x0 + R)
 	// LDS offset of the tap at (row offset ro, column offset co) relative to the pixel's base pointer (row yy-Y0, column slot x-x0+R)
 	static constexpr int tap(int ro, int co) { return ((K0 + co) % SKIP) * plane + ro * IWp + (K0 + co) / SKIP; }
@@ -358,14 +361,50 @@ __device__ __forceinline__ f32x2 fusedInnerDet2(const float* c) {
 	return Dxx * Dyy - 0.81f * Dxy * Dxy;
 }
 
-template <class G, int SKIP, int NL, int R, int L, class T>
-__device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const T* iiT, float* inten, int tid, int x0, int y0, int X0, int Y0) {
-	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), border = G::border(L);
+// Intensity of level L at intensity-space pixel (x, y), any position class: -inf outside the image (never >= anything, as if the
+// neighbourhood were clamped), the unrolled inner form (hessianInner) for inner pixels, the clamped border form (hessianBorder) otherwise
+template <class G, int SKIP, int L, class T>
+__device__ __forceinline__ float fusedPixel(int W, int H, int pw, int ph, const T* iiT, int x, int y, int x0, int y0, int X0, int Y0) {
+	constexpr int size = G::size(L), bS = G::bS(L), bLg = G::bL(L), border = G::border(L), R = G::HALO;
 	constexpr float norm = 1.0f / (float)(size * size);
-	constexpr int pitch = G::IWp;
 	constexpr int r1 = bS / 2, r2 = bS + r1, r3 = bLg / 2, b = bS;
-	float* out = inten + L * G::ITH * G::ITp;
-	const int W = P.ii.width, H = P.ii.height;
+	if (x < 0 || x >= pw || y < 0 || y >= ph) return -INFINITY;
+	const int xx = x * SKIP, yy = y * SKIP;
+	const bool inner = x >= border && x < pw - border && y >= border && y < ph - border;
+	if (inner) return fusedInnerDet<G, L, T>(iiT + (yy - Y0) * G::IWp + (x - x0 + R));
+	float Dxx, Dyy, Dxy;
+	T ret = 0;
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * T(1);
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * T(-3);
+	Dxx = (float)ret;
+	ret = 0;
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * T(1);
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * T(-3);
+	Dyy = (float)ret;
+	ret = 0;
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * T(1);
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * T(-1);
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * T(1);
+	ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * T(-1);
+	Dxy = (float)ret;
+	Dxx *= norm;
+	Dxy *= norm;
+	Dyy *= norm;
+	return Dxx * Dyy - 0.81f * Dxy * Dxy;
+}
+
+// Out-of-line form for the rare callers (frame tiles, NMS survivors, exported outer levels): one copy of the 32-tap body + the border
+// formula per level instead of one per call site keeps the kernel's register count at what the dense loop needs.
+template <class G, int SKIP, int L, class T>
+__device__ __noinline__ float fusedPixelCall(int W, int H, int pw, int ph, const T* iiT, int x, int y, int x0, int y0, int X0, int Y0) {
+	return fusedPixel<G, SKIP, L, T>(W, H, pw, ph, iiT, x, y, x0, y0, X0, Y0);
+}
+
+// Dense intensity tile (core + halo) of level L into `out` ([ITH][ITp])
+template <class G, int SKIP, int R, int L, class T>
+__device__ __forceinline__ void fusedLevelDense(const FusedParams& P, const T* iiT, float* out, int tid, int x0, int y0, int X0, int Y0) {
+	constexpr int border = G::border(L);
+	constexpr int pitch = G::IWp;
 	// tile + halo entirely made of inner pixels of this level (true for all but the tiles along the image frame): no per-pixel tests
 	const bool interior = x0 - R >= border && x0 + G::TX + R <= P.w - border && y0 - R >= border && y0 + G::TY + R <= P.h - border;
 	if (interior) {
@@ -389,41 +428,54 @@ __device__ __forceinline__ void fusedLevelFixed(const FusedParams& P, const T* i
 #pragma unroll 1
 		for (int it = tid; it < G::ITH * G::ITW; it += 256) {
 			const int px = it & (G::ITW - 1), py = it / G::ITW;
-			const int x = x0 - R + px, y = y0 - R + py;
-			float det;
-			if (x < 0 || x >= P.w || y < 0 || y >= P.h) {
-				det = -INFINITY;   // outside the image: never >= anything, as if the neighbourhood were clamped
-			} else {
-				const int xx = x * SKIP, yy = y * SKIP;
-				const bool inner = x >= border && x < P.w - border && y >= border && y < P.h - border;
-				if (inner) {
-					det = fusedInnerDet<G, L, T>(iiT + (yy - Y0) * pitch + (x - x0 + R));
-				} else {
-					float Dxx, Dyy, Dxy;
-					T ret = 0;
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r2 - 1, yy - r3 - 1, xx + r2, yy + r3) * T(1);
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r1 - 1, yy - r3 - 1, xx + r1, yy + r3) * T(-3);
-					Dxx = (float)ret;
-					ret = 0;
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r2 - 1, xx + r3, yy + r2) * T(1);
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - r3 - 1, yy - r1 - 1, xx + r3, yy + r1) * T(-3);
-					Dyy = (float)ret;
-					ret = 0;
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - b - 1, yy - b - 1, xx - 1, yy - 1) * T(1);
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx, yy - b - 1, xx + b, yy - 1) * T(-1);
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx, yy, xx + b, yy + b) * T(1);
-					ret += pblock_zero<G, T>(iiT, X0, Y0, W, H, xx - b - 1, yy, xx - 1, yy + b) * T(-1);
-					Dxy = (float)ret;
-					Dxx *= norm;
-					Dxy *= norm;
-					Dyy *= norm;
-					det = Dxx * Dyy - 0.81f * Dxy * Dxy;
-				}
-			}
-			out[py * G::ITp + px] = det;
+			out[py * G::ITp + px] = fusedPixelCall<G, SKIP, L, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x0 - R + px, y0 - R + py, x0, y0, X0, Y0);
 		}
 	}
-	if constexpr (L + 1 < NL) fusedLevelFixed<G, SKIP, NL, R, L + 1, T>(P, iiT, inten, tid, x0, y0, X0, Y0);
+}
+
+// checkMax on the lower and the upper level + polyPeak fits + emission for an NMS survivor of mid slot m at tile pixel (px, py):
+// FastHessianFeatureDetector.findLocalScaleSpaceMax :278-297.  The outer level on the far side of the mid level (level 0 below mid level 1,
+// level 3 above mid level 2) arrives as "all nine neighbours below val" + its centre value; the other neighbour level is the other dense
+// mid level.
+template <class G, int SKIP, int R>
+__device__ __forceinline__ void fusedFinish(const FusedParams& P, const float* mid1, const float* mid2, bool outerBelow, float outerCentre, int m, int px, int py,
+											int x, int y, float val, int img) {
+	const FusedMid M = P.mid[m];
+	const bool lowMid = M.level == 1;
+	const float* self = (lowMid ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
+	const float* other = (lowMid ? mid2 : mid1) + (py + R) * G::ITp + (px + R);
+	if (!outerBelow) return;
+	float dn[9];
+	bool ok = true;
+#pragma unroll
+	for (int q = 0; q < 9; q++) {
+		dn[q] = other[(q / 3 - 1) * G::ITp + (q % 3 - 1)];
+		if (dn[q] >= val) ok = false;
+	}
+	if (!ok) return;
+	const float lowerC = lowMid ? outerCentre : dn[4], upperC = lowMid ? dn[4] : outerCentre;
+	const float peakX = fpolyPeak(self[-1], val, self[1]);
+	const float peakY = fpolyPeak(self[-G::ITp], val, self[G::ITp]);
+	const float peakS = fpolyPeak(lowerC, val, upperC);
+	const float interpX = ((float)x + peakX) * (float)SKIP;
+	const float interpY = ((float)y + peakY) * (float)SKIP;
+	const float interpS = (float)M.sizeMid + peakS * (float)(M.sizeMid - M.sizeLower);
+	const double scale = 1.2 * (double)interpS / 9.0;
+	constexpr int step = R + 1;
+	if (BHIP_ABLATE(P, 7)) return;   // timing experiments run on garbage: never emit
+	const int b = M.border;
+	const unsigned int bit = M.bitBase + (unsigned)((y - b) / step) * (unsigned)M.nbx + (unsigned)((x - b) / step);
+	atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+	const int slot = atomicAdd(&P.candCount[img], 1);
+	if (slot < P.cap) {
+		KeyPoint kp;
+		kp.x = (double)interpX;
+		kp.y = (double)interpY;
+		kp.scale = scale;
+		kp.key = bit;
+		kp.pad = 0;
+		P.cand[(long long)img * P.cap + slot] = kp;
+	}
 }
 
 template <class T, int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
@@ -431,7 +483,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	typedef FixedGeo<SKIP, SIZE0, STEPSZ, NL, R, ITWT, TYT> G;
 	extern __shared__ __attribute__((aligned(16))) float fl[];
 	T* iiT = (T*)fl;   // 32-bit words either way
-	float* inten = fl + SKIP * G::plane;
+	float* inten = fl + SKIP * G::plane;   // the two dense mid levels, then the survivor list and its sparse outer-level values
 	const int tid = threadIdx.x;
 	// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one L2), so block b takes
 	// tile (b % 8) * chunk + b / 8 -- every XCD walks its own contiguous run of tiles (row after row of one image) and the halo
@@ -521,10 +573,24 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		}
 	}
 	__syncthreads();
-	if (!BHIP_ABLATE(P, 1)) fusedLevelFixed<G, SKIP, NL, R, 0, T>(P, iiT, inten, tid, x0, y0, X0, Y0);
+	// ---- intensity.  The 3x3x3 scale-space test only ever looks at the outer levels (0 and 3) in the 3x3 neighbourhood of a pixel that is
+	// already a strict (2R+1)^2 maximum of a mid level (1 or 2), so only the two mid levels are built densely over the tile; the outer
+	// levels are evaluated on demand at the few NMS survivors (nine values each).  Same functions of (pixel, kernel size), same decisions.
+	static_assert(NL == 4, "two mid levels between two outer levels");
+	float* mid1 = inten;                          // level 1  [ITH][ITp]
+	float* mid2 = inten + G::ITH * G::ITp;        // level 2
+	int* survList = (int*)(inten + 2 * G::ITH * G::ITp);   // [SURV] packed (m << 16 | py << 8 | px)
+	float* sparse = (float*)(survList + G::SURV);          // [SURV][9] outer-level values around each survivor
+	int* survCount = (int*)(sparse + G::CHUNK * 9);
+	if (tid == 0) *survCount = 0;
+	if (!BHIP_ABLATE(P, 1)) {
+		fusedLevelDense<G, SKIP, R, 1, T>(P, iiT, mid1, tid, x0, y0, X0, Y0);
+		fusedLevelDense<G, SKIP, R, 2, T>(P, iiT, mid2, tid, x0, y0, X0, Y0);
+	}
 	__syncthreads();
 	if (P.nexp > 0) {
-		// even pixels of the tile core -> pixel (x/2, y/2) of the next octave
+		// even pixels of the tile core -> pixel (x/2, y/2) of the next octave.  A mid level is read from its tile, an outer level is
+		// evaluated here (a quarter of the core's pixels).
 		constexpr int HX = (G::TX + 1) / 2, HY = (G::TY + 1) / 2;
 		const int ex0 = (x0 + 1) >> 1, ey0 = (y0 + 1) >> 1;   // first even pixel of the core, in next-octave coordinates
 		for (int it = tid; it < P.nexp * HX * HY; it += 256) {
@@ -533,78 +599,78 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			const int jy = rem / HX, jx = rem - jy * HX;
 			const int ex = ex0 + jx, ey = ey0 + jy;
 			const int px = 2 * ex - x0, py = 2 * ey - y0;   // core coordinates in this tile
-			if (px < G::TX && py < G::TY && 2 * ex < P.w && 2 * ey < P.h && ex < P.expW && ey < P.expH)
-				P.expOut[(long long)img * P.expImageStride + ((long long)k * P.expH + ey) * P.expW + ex] =
-					inten[P.expLevel[k] * (G::ITH * G::ITp) + (py + R) * G::ITp + (px + R)];
+			if (px < G::TX && py < G::TY && 2 * ex < P.w && 2 * ey < P.h && ex < P.expW && ey < P.expH) {
+				const int lv = P.expLevel[k];
+				float v;
+				if (lv == 1) v = mid1[(py + R) * G::ITp + (px + R)];
+				else if (lv == 2) v = mid2[(py + R) * G::ITp + (px + R)];
+				else if (lv == 0) v = fusedPixelCall<G, SKIP, 0, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x0 + px, y0 + py, x0, y0, X0, Y0);
+				else v = fusedPixelCall<G, SKIP, 3, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x0 + px, y0 + py, x0, y0, X0, Y0);
+				P.expOut[(long long)img * P.expImageStride + ((long long)k * P.expH + ey) * P.expW + ex] = v;
+			}
 		}
 	}
 
-	// candidates: ITW-wide rows of lanes (ITW <= 64 is a power of two), so a wave covers 64 / ITW tile rows per pass
-	const int rows = BHIP_ABLATE(P, 2) ? 0 : P.nmid * G::TY;
-	for (int it = tid; it < rows * G::ITW; it += 256) {
-		const int row = it / G::ITW;
-		const int px = it & (G::ITW - 1);
-		const int m = row / G::TY;
-		const int py = row - m * G::TY;
-		if (px >= G::TX) continue;
-		const FusedMid M = P.mid[m];
-		const int x = x0 + px, y = y0 + py;
-		const int b = M.border;
-		if (x < b || x >= P.w - b || y < b || y >= P.h - b) continue;
-		const float* mid = inten + M.level * (G::ITH * G::ITp) + (py + R) * G::ITp + (px + R);
-		const float val = mid[0];
-		if (!(val >= P.threshold) || val == FLT_MAX) continue;
-		// most pixels above the threshold lose against a direct neighbour: four reads settle them before the full window is fetched
-		{
-			const float n0 = mid[-1], n1 = mid[1], n2 = mid[-G::ITp], n3 = mid[G::ITp];
-			if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) continue;
+	// ---- strict (2R+1)^2 maxima of the two mid levels.  Thread = one core column of one (level, row-phase) slice; rows are walked with the
+	// threshold test first: almost every pixel ends there with one LDS read.
+	{
+		constexpr int SL = 256 / G::ITW;           // row slices a pass of 256 threads covers (ITW lanes per row)
+		const int px = tid & (G::ITW - 1), slice = tid / G::ITW;
+		const int x = x0 + px;
+		for (int row = slice; row < P.nmid * G::TY && !BHIP_ABLATE(P, 2); row += SL) {
+			const int m = row / G::TY, py = row - m * G::TY;
+			if (px >= G::TX) continue;
+			const float* mid = (P.mid[m].level == 1 ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
+			const float val = mid[0];
+			if (!(val >= P.threshold) || val == FLT_MAX) continue;
+			const int b = P.mid[m].border;
+			const int y = y0 + py;
+			if (x < b || x >= P.w - b || y < b || y >= P.h - b) continue;
+			// most pixels above the threshold lose against a direct neighbour: four reads settle them before the full window is fetched
+			{
+				const float n0 = mid[-1], n1 = mid[1], n2 = mid[-G::ITp], n3 = mid[G::ITp];
+				if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) continue;
+			}
+			bool isMax = true;
+#pragma unroll
+			for (int j = -R; j <= R; j++)
+#pragma unroll
+				for (int i = -R; i <= R; i++)
+					if ((i != 0 || j != 0) && mid[j * G::ITp + i] >= val) isMax = false;
+			if (!isMax) continue;
+			// candidates hugging the ignore border are dropped (FastHessianFeatureDetector.java:270-276)
+			const int ignoreR = b + R;
+			if (x < ignoreR || x >= P.w - ignoreR || y < ignoreR || y >= P.h - ignoreR) continue;
+			// two strict (2R+1)^2 maxima are more than R apart: at most one per (R+1)^2 block, SURV = 2 * blocks per tile holds them all
+			const int slot = atomicAdd(survCount, 1);
+			if (slot < G::SURV) survList[slot] = (m << 16) | (py << 8) | px;
 		}
-		// the whole (2R+1)^2 neighbourhood in one batch of LDS reads
-		float nb[(2 * R + 1) * (2 * R + 1)];
-#pragma unroll
-		for (int j = -R; j <= R; j++)
-#pragma unroll
-			for (int i = -R; i <= R; i++) nb[(j + R) * (2 * R + 1) + (i + R)] = mid[j * G::ITp + i];
-		bool isMax = true;
-#pragma unroll
-		for (int k = 0; k < (2 * R + 1) * (2 * R + 1); k++)
-			if (k != R * (2 * R + 1) + R && nb[k] >= val) isMax = false;
-		if (!isMax) continue;
-		const int ignoreR = b + R;
-		if (x < ignoreR || x >= P.w - ignoreR || y < ignoreR || y >= P.h - ignoreR) continue;
-		const float* lower = mid - G::ITH * G::ITp;
-		const float* upper = mid + G::ITH * G::ITp;
-		float lo9[9], up9[9];
-#pragma unroll
-		for (int j = -1; j <= 1; j++)
-#pragma unroll
-			for (int i = -1; i <= 1; i++) { lo9[(j + 1) * 3 + i + 1] = lower[j * G::ITp + i]; up9[(j + 1) * 3 + i + 1] = upper[j * G::ITp + i]; }
-		bool ok = true;
-#pragma unroll
-		for (int k = 0; k < 9; k++)
-			if (lo9[k] >= val || up9[k] >= val) ok = false;
-		if (!ok) continue;
-		const float peakX = fpolyPeak(nb[R * (2 * R + 1) + R - 1], val, nb[R * (2 * R + 1) + R + 1]);
-		const float peakY = fpolyPeak(nb[(R - 1) * (2 * R + 1) + R], val, nb[(R + 1) * (2 * R + 1) + R]);
-		const float peakS = fpolyPeak(lo9[4], val, up9[4]);
-		const float interpX = ((float)x + peakX) * (float)SKIP;
-		const float interpY = ((float)y + peakY) * (float)SKIP;
-		const float interpS = (float)M.sizeMid + peakS * (float)(M.sizeMid - M.sizeLower);
-		const double scale = 1.2 * (double)interpS / 9.0;
-		constexpr int step = R + 1;
-		if (BHIP_ABLATE(P, 7)) continue;   // timing experiments run on garbage: never emit
-		const unsigned int bit = M.bitBase + (unsigned)((y - b) / step) * (unsigned)M.nbx + (unsigned)((x - b) / step);
-		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
-		const int slot = atomicAdd(&P.candCount[img], 1);
-		if (slot < P.cap) {
-			KeyPoint kp;
-			kp.x = (double)interpX;
-			kp.y = (double)interpY;
-			kp.scale = scale;
-			kp.key = bit;
-			kp.pad = 0;
-			P.cand[(long long)img * P.cap + slot] = kp;
+	}
+	__syncthreads();
+	const int nSurv = min(*survCount, G::SURV);
+	for (int base = 0; base < nSurv; base += G::CHUNK) {   // one round for all but the densest tiles
+		const int nHere = min(G::CHUNK, nSurv - base);
+		// ---- outer level around every survivor: nine values each, one (survivor, neighbour) pair per thread
+		for (int it = tid; it < nHere * 9; it += 256) {
+			const int sv = it / 9, q = it - sv * 9;
+			const int code = survList[base + sv];
+			const int m = code >> 16, py = (code >> 8) & 0xff, px = code & 0xff;
+			const int x = x0 + px + q % 3 - 1, y = y0 + py + q / 3 - 1;
+			sparse[it] = P.mid[m].level == 1 ? fusedPixelCall<G, SKIP, 0, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0)
+											 : fusedPixelCall<G, SKIP, 3, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0);
 		}
+		__syncthreads();
+		for (int sv = tid; sv < nHere; sv += 256) {
+			const int code = survList[base + sv];
+			const int m = code >> 16, py = (code >> 8) & 0xff, px = code & 0xff;
+			const float val = (P.mid[m].level == 1 ? mid1 : mid2)[(py + R) * G::ITp + (px + R)];
+			bool below = true;
+#pragma unroll
+			for (int q = 0; q < 9; q++)
+				if (sparse[sv * 9 + q] >= val) below = false;
+			fusedFinish<G, SKIP, R>(P, mid1, mid2, below, sparse[sv * 9 + 4], m, px, py, x0 + px, y0 + py, val, img);
+		}
+		if (base + G::CHUNK < nSurv) __syncthreads();
 	}
 }
 

@@ -27,6 +27,7 @@ struct ConvParams {
 	int unrolled;   // first tap assigns instead of adding to 0
 	int mode;       // 0 = no border (frame untouched), 1 = normalised border, 2 = normalised naive (kernel wider than image),
 	                // 3 = normalised border pixels only (interior untouched: the mean blur fills it with running sums)
+	int borderOnly; // general kernel only: the grid covers just the koff + (kw-koff-1) border columns (rows) of the filtered axis
 	float k[BHIP_MAX_TAPS];
 };
 
@@ -70,12 +71,18 @@ __device__ __forceinline__ float tapsStandard(const float* __restrict__ s, long 
 // kernels wider than the image); the tiled kernels below take over whenever rows are 16-byte aligned.
 template <bool VERTICAL>
 __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
-	const int x = blockIdx.x * blockDim.x + threadIdx.x;
-	const int y = blockIdx.y;
-	if (x >= P.width) return;
-	const int pos = VERTICAL ? y : x;
+	int x = blockIdx.x * blockDim.x + threadIdx.x;
+	int y = blockIdx.y;
 	const int extent = VERTICAL ? P.height : P.width;
 	const int offL = P.koff, offR = P.kw - P.koff - 1;
+	if (P.borderOnly) {
+		// border fix-up after a streaming kernel: index t of the filtered axis runs over the offL leading and offR trailing positions
+		int& t = VERTICAL ? y : x;
+		if (t >= offL + offR) return;
+		t = t < offL ? t : extent - offR + (t - offL);
+	}
+	if (x >= P.width) return;
+	const int pos = VERTICAL ? y : x;
 	const long long step = VERTICAL ? P.inStride : 1;
 	const float* src = P.in + (long long)blockIdx.z * P.inImageStride + (long long)y * P.inStride + x;
 	const bool interior = pos >= offL && pos < extent - offR;
@@ -249,27 +256,22 @@ __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
 	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride;
 	const int yEnd = min(y0 + CS_ROWS, P.height);
-	const bool allInterior = x >= R && x + 3 < P.width - R && P.mode != 3;
-	if (!allInterior) {
-		// strips that touch the left / right border (or hold the row's tail): the general per-pixel rules, taps through L1
-		for (int y = y0; y < yEnd; y++) {
+	// interior pixels only: the border columns (normalised forms) are written afterwards by the general kernel (borderOnly launch)
+	const bool allInterior = x >= R && x + 3 < P.width - R;
+	// two row buffers take turns: while row y is filtered and stored, the chunks of rows y+1 and y+2 are in flight
+	float4 bufA[NL], bufB[NL];
+	auto fetch = [&](float4 (&buf)[NL], int y) {
+		if (y < yEnd) {
 			const float* row = img + (long long)y * P.inStride;
-			float* dst = outImg + (long long)y * P.outStride + x;
-			for (int j = 0; j < 4 && x + j < P.width; j++) {
-				float r;
-				if (convOne<KW>(P, row + x + j - R, 1, x + j, P.width, r)) dst[j] = r;
-			}
+#pragma unroll
+			for (int c = 0; c < NL; c++) buf[c] = loadRow4(row, x - PL + 4 * c, P.width);
 		}
-		return;
-	}
-	for (int y = y0; y < yEnd; y++) {
-		const float* row = img + (long long)y * P.inStride;
+	};
+	auto emit = [&](const float4 (&buf)[NL], int y) {
+		if (y >= yEnd) return;
 		float v[4 * NL];
 #pragma unroll
-		for (int c = 0; c < NL; c++) {
-			const float4 q = loadRow4(row, x - PL + 4 * c, P.width);
-			v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
-		}
+		for (int c = 0; c < NL; c++) { v[4 * c] = buf[c].x; v[4 * c + 1] = buf[c].y; v[4 * c + 2] = buf[c].z; v[4 * c + 3] = buf[c].w; }
 		float r[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
@@ -278,17 +280,31 @@ __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 			for (int i = 1; i < KW; i++) total += v[PL - R + j + i] * P.k[i];
 			r[j] = total;
 		}
-		*reinterpret_cast<float4*>(outImg + (long long)y * P.outStride + x) = make_float4(r[0], r[1], r[2], r[3]);
+		float* dst = outImg + (long long)y * P.outStride + x;
+		if (allInterior) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+		else {
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				if (x + j >= R && x + j < P.width - R) dst[j] = r[j];
+		}
+	};
+	fetch(bufA, y0);
+	fetch(bufB, y0 + 1);
+	for (int y = y0; y < yEnd; y += 2) {
+		emit(bufA, y);
+		fetch(bufA, y + 2);
+		emit(bufB, y + 1);
+		fetch(bufB, y + 3);
 	}
 }
 
 // Vertical: lane l owns columns 4l..4l+3 and walks a strip of CS_ROWS_V output rows with the KW input rows of the current output in a
-// register ring of KW+1 slots (the extra slot receives the next row while the current output is computed).  Strips that touch the top or
+// register ring of KW+2 slots (the two extra slots receive the rows of the next two outputs while the current one is computed).  Strips that touch the top or
 // bottom border evaluate the border rules per row from the same ring.
 #define CS_ROWS_V 32
 template <int KW>
 __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
-	constexpr int R = KW / 2, RING = KW + 1;
+	constexpr int R = KW / 2, RING = KW + 2;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int x = blockIdx.x * 256 + 4 * lane;
 	const int y0 = (blockIdx.y * 4 + wave) * CS_ROWS_V;
@@ -301,28 +317,16 @@ __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
 		if (yy < 0 || yy >= P.height) return make_float4(0, 0, 0, 0);
 		return loadRow4(img + (long long)yy * P.inStride - x, x, P.width);
 	};
-	const bool interiorStrip = y0 >= R && yEnd + R <= P.height && P.mode != 3;
-	if (!interiorStrip) {
-		// top / bottom strips: the general per-pixel rules, taps through L1
-		for (int y = y0; y < yEnd; y++) {
-			float* dst = outImg + (long long)y * P.outStride;
-			for (int q = 0; q < 4 && x + q < P.width; q++) {
-				float r;
-				if (convOne<KW>(P, img + (long long)(y - R) * P.inStride + q, P.inStride, y, P.height, r)) dst[q] = r;
-			}
-		}
-		return;
-	}
 	float4 ring[RING];
 	// ring[(t + i) % RING] = input row y0 - R + t + i, the tap i of output row y0 + t
 #pragma unroll
-	for (int i = 0; i < KW - 1; i++) ring[i] = loadRow(y0 - R + i);
+	for (int i = 0; i < KW + 1; i++) ring[i] = loadRow(y0 - R + i);
 	for (int tb = 0; y0 + tb < yEnd; tb += RING) {
 #pragma unroll
 		for (int j = 0; j < RING; j++) {
 			const int y = y0 + tb + j;
 			if (y < yEnd) {
-				ring[(j + KW - 1) % RING] = loadRow(y + R);
+				if (y + 2 < yEnd) ring[(j + KW + 1) % RING] = loadRow(y + 2 + R);   // a spare slot receives the last tap of the output after next
 				float r[4];
 				const float4 t0 = ring[j % RING];
 				r[0] = t0.x * P.k[0]; r[1] = t0.y * P.k[0]; r[2] = t0.z * P.k[0]; r[3] = t0.w * P.k[0];
@@ -331,10 +335,12 @@ __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
 					const float4 t = ring[(j + i) % RING];
 					r[0] += t.x * P.k[i]; r[1] += t.y * P.k[i]; r[2] += t.z * P.k[i]; r[3] += t.w * P.k[i];
 				}
-				float* dst = outImg + (long long)y * P.outStride;
-				if (full4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
-				else
-					for (int q = 0; q < 4 && x + q < P.width; q++) dst[q] = r[q];
+				if (y >= R && y < P.height - R) {   // interior rows only: the border rows are written by the general kernel (borderOnly launch)
+					float* dst = outImg + (long long)y * P.outStride;
+					if (full4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+					else
+						for (int q = 0; q < 4 && x + q < P.width; q++) dst[q] = r[q];
+				}
 			}
 		}
 	}
@@ -352,6 +358,7 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 	for (int i = 0; i < kw; i++) P.k[i] = kernel[i];
 	P.unrolled = (koff == kw / 2 && kw % 2 == 1 && (kw == 3 || kw == 5 || kw == 7 || kw == 9 || kw == 11)) ? 1 : 0;
 	P.mode = 0;
+	P.borderOnly = 0;
 	if (normalized) {
 		const int extent = vertical ? height : width;
 		if (kw >= extent) {
@@ -395,6 +402,12 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 		default: LAUNCH_S(11); break;
 		}
 #undef LAUNCH_S
+		if (P.mode == 1) {
+			// the kw - 1 border columns (rows) with the re-normalised formula: a thin launch of the general kernel
+			P.borderOnly = 1;
+			if (vertical) hipLaunchKernelGGL(k_conv<true>, dim3((width + 255) / 256, kw - 1, batch), dim3(256), 0, ctx->stream, P);
+			else hipLaunchKernelGGL(k_conv<false>, dim3(1, height, batch), dim3(256), 0, ctx->stream, P);
+		}
 	} else if (vertical) {
 		dim3 grid((width + CT_W - 1) / CT_W, (height + CV_ROWS - 1) / CV_ROWS, batch);
 		const size_t ldsBytes = (size_t)(CV_ROWS + kw - 1) * CT_W * 4;
@@ -667,10 +680,12 @@ __global__ __launch_bounds__(256) void k_grad_stream(GradParams P) {
 	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
 	float* dxImg = P.dx + (long long)blockIdx.z * P.outImageStride;
 	float* dyImg = P.dy + (long long)blockIdx.z * P.outImageStride;
-	GradRow r0 = gradLoadRow(P, img, x, y0 - 1, lane), r1 = gradLoadRow(P, img, x, y0, lane);
+	GradRow r0 = gradLoadRow(P, img, x, y0 - 1, lane), r1 = gradLoadRow(P, img, x, y0, lane), r2 = gradLoadRow(P, img, x, y0 + 1, lane);
 	const int yEnd = min(y0 + GR_ROWS, P.height);
 	for (int y = y0; y < yEnd; y++) {
-		const GradRow r2 = gradLoadRow(P, img, x, y + 1, lane);
+		// row y+2 (the bottom row of the NEXT output) is requested before this output is computed: one row of loads always in flight
+		GradRow r3 = r2;
+		if (y + 1 < yEnd) r3 = gradLoadRow(P, img, x, y + 2, lane);
 		if (x < P.width) {
 			float dx[4], dy[4];
 			bool wr[4];
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(256) void k_grad_stream(GradParams P) {
 					if (x + j < P.width && wr[j]) { dxImg[o + j] = dx[j]; dyImg[o + j] = dy[j]; }
 			}
 		}
-		r0 = r1; r1 = r2;
+		r0 = r1; r1 = r2; r2 = r3;
 	}
 }
 
@@ -1067,7 +1082,7 @@ int bhip_launch_mean(bhip_ctx* ctx, bool vertical, const float* in, float* out, 
 	{
 		ConvParams P;
 		P.in = in; P.out = out; P.inStride = width; P.outStride = width; P.width = width; P.height = height; P.kw = kw; P.koff = radius;
-		P.inImageStride = 0; P.outImageStride = 0;
+		P.inImageStride = 0; P.outImageStride = 0; P.borderOnly = 0;
 		for (int i = 0; i < kw; i++) P.k[i] = ker[i];
 		P.unrolled = 0; P.mode = 3;
 		dim3 grid((width + 255) / 256, height);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/config1_small.npz: a frozen run of BASELINE config 1 (two S-noise frames through surfStable, greedy mutual-best
-Euclidean-squared association), scaled down to 320x240 so the file stays small.
+"""Writes tests/golden/config1_small.npz and config1_640x480.npz: frozen runs of BASELINE config 1 (two S-noise frames through surfStable,
+greedy mutual-best Euclidean-squared association) -- scaled down to 320x240, and at the configuration's real 640x480 (there every
+8th descriptor is stored, plus the row sum of every descriptor, to keep the file small).
 
 IMPORTANT: the vectors come from oracle/ -- the C++ restatement of the reference's Java code -- NOT from BoofCV itself.  This image has no
 JVM and the reference ships no stored outputs, so these fixtures cannot pin parity with the Java build; they pin the
@@ -22,22 +23,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 W, H, SEEDS = 320, 240, (234, 235)
+FULL_W, FULL_H = 640, 480     # BASELINE config 1 at its real size (config1_640x480.npz)
+FULL_DESC_EVERY = 8           # the full-size fixture stores every 8th descriptor (+ a row sum of every descriptor) to stay small
 
 
-def generate():
+def generate(width=W, height=H, desc_every=1):
     from oracle import pyoracle as orc
     orc.build()
     out = {}
     descs = []
     for k, seed in enumerate(SEEDS):
-        img = orc.noise_image(W, H, seed)
+        img = orc.noise_image(width, height, seed)
         s = orc.Surf(True)
         n = s.detect(img)
         xys, ang, white, desc = s.fetch()
         out["xys%d" % k] = xys
         out["angle%d" % k] = ang
         out["white%d" % k] = white.astype(np.uint8)
-        out["desc%d" % k] = desc.astype(np.float32)
+        out["desc%d" % k] = desc[::desc_every].astype(np.float32)
+        if desc_every > 1:
+            out["descsum%d" % k] = desc.sum(axis=1)      # float64 row sums of ALL descriptors: a cheap check of the ones not stored
         descs.append(desc)
         if k == 0:
             sp, cp = orc.brief_definition()
@@ -49,7 +54,9 @@ def generate():
 
 
 if __name__ == "__main__":
-    data = generate()
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config1_small.npz")
-    np.savez_compressed(path, **data)
-    print(path, {k: v.shape for k, v in data.items()}, os.path.getsize(path), "bytes")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, args in (("config1_small.npz", (W, H, 1)), ("config1_640x480.npz", (FULL_W, FULL_H, FULL_DESC_EVERY))):
+        data = generate(*args)
+        path = os.path.join(here, name)
+        np.savez_compressed(path, **data)
+        print(path, {k: v.shape for k, v in data.items()}, os.path.getsize(path), "bytes")

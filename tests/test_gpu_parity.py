@@ -206,12 +206,14 @@ def _compare_surf(api, orc, dd, ref, img, image_index=0):
     assert np.array_equal(got[0], xys)          # location + scale: bit exact, reference order
     assert np.array_equal(got[2], white)        # Laplacian sign
     if n:
+        # No exception list: with the wave-parallel window sweep handing every trailing-side window to the serial reference sweep, every
+        # orientation agrees with the oracle to a few ulp (measured max 2.2e-15 rad over 110 k key points) and every descriptor value to
+        # ~5e-16.  The north-star bar is 1e-5; the orientation bar below is 1e-12 rad for EVERY key point.
         dang = np.abs(np.angle(np.exp(1j * (got[1] - ang))))
         derr = np.max(np.abs(got[3] - desc), axis=1)
-        ok = derr <= DESC_TOL
-        # a last-ulp difference in atan2/sin/cos can move one sample across a pixel boundary (SURVEY hard part 4): allow 0.1 % outliers
-        assert ok.mean() >= 0.999, "descriptor outlier rate %.4f, max err %.3g" % (1 - ok.mean(), derr.max())
-        assert np.median(dang) < 1e-12
+        nout = int((derr > DESC_TOL).sum())
+        assert nout == 0, "descriptors outside 1e-5: %d of %d, max err %.3g, their angle errors %s" % (nout, n, derr.max(), dang[derr > DESC_TOL][:5])
+        assert dang.max() < 1e-12, "orientation max err %.3g rad at key point %d" % (dang.max(), int(dang.argmax()))
         assert np.allclose(np.linalg.norm(got[3], axis=1), 1, atol=1e-12)
     return n
 
@@ -818,7 +820,7 @@ def test_surf_color_planar_parity(api, orc, stable):
         assert np.array_equal(got[0], pts) and np.array_equal(got[2], white)
         assert np.max(np.abs(np.angle(np.exp(1j * (got[1] - ang))))) < 1e-9
         derr = np.max(np.abs(got[3] - desc), axis=1)
-        assert (derr <= DESC_TOL).mean() >= 0.999, (w, h, nb, derr.max())
+        assert int((derr > DESC_TOL).sum()) == 0, (w, h, nb, int((derr > DESC_TOL).sum()), derr.max())
         assert dd.getRadius(0) == pts[0, 2] and dd.getOrientation(0) == got[1][0]
         # sub-image bands (shared startIndex / stride)
         dd.detect(api.Planar.wrap([G(api, b.sub_image_of()) for b in bands]))
@@ -956,9 +958,9 @@ def test_surf_on_gray_u8(api, orc, stable):
         n = ref.detect_u8(img, threads=8)
         pts, ang, white, desc = ref.fetch()
         assert n > 100 and np.array_equal(got[0], pts) and np.array_equal(got[2], white)
-        assert np.median(np.abs(np.angle(np.exp(1j * (got[1] - ang))))) < 1e-12
+        assert np.abs(np.angle(np.exp(1j * (got[1] - ang)))).max() < 1e-12
         derr = np.max(np.abs(got[3] - desc), axis=1)
-        assert (derr <= DESC_TOL).mean() >= 0.999, (img.shape, derr.max())
+        assert int((derr > DESC_TOL).sum()) == 0, (img.shape, int((derr > DESC_TOL).sum()), derr.max())
     # batch of equal-sized frames == frame by frame; sub-image input
     a, b = frames[0], np.ascontiguousarray(frames[1][:200, :240])
     dd.detectBatch([api.GrayU8.wrap(a), api.GrayU8.wrap(b)])
