@@ -482,6 +482,38 @@ class DetectDescribePoint:
             self._cache[image] = (xys, ang, white, desc)
         return self._cache[image]
 
+    def fetchAll(self):
+        """The whole batch of the last detect in one set of copies (bhip_surf_fetch_all): (xy_scale [total,3], angle [total],
+        white [total], desc [total,dof], starts [batch+1]); image i owns rows starts[i]:starts[i+1]."""
+        L = _lib.load()
+        counts = np.zeros(self._batch, dtype=np.int32)
+        n = C.c_int(0)
+        for i in range(self._batch):
+            _check(self.ctx, L.bhip_surf_count(self._h, i, C.byref(n)))
+            counts[i] = n.value
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        total = int(starts[-1])
+        xys = np.zeros((total, 3)); ang = np.zeros(total); white = np.zeros(total, dtype=np.uint8); desc = np.zeros((total, self._dof))
+        if total:
+            _check(self.ctx, L.bhip_surf_fetch_all(self._h, xys.ctypes.data_as(_lib._dp), ang.ctypes.data_as(_lib._dp), white.ctypes.data_as(_lib._u8p),
+                                                   desc.ctypes.data_as(_lib._dp)))
+        return xys, ang, white, desc, starts
+
+    def associateImages(self, srcImages, dstImages, maxError=Double_MAX_VALUE, backwardsValidation=True):
+        """Greedy Euclidean-squared association of image srcImages[p] with image dstImages[p] of the last detect, on the descriptors still
+        resident on the device (bhip_assoc_l2_surf).  -> (pairs, fitQuality) over the batch's compact key-point index space (see fetchAll)."""
+        L = _lib.load()
+        a = np.ascontiguousarray(srcImages, dtype=np.int32)
+        b = np.ascontiguousarray(dstImages, dtype=np.int32)
+        if a.shape != b.shape:
+            raise IllegalArgumentException("source and destination image lists differ in length")
+        total = max(self.totalFeatures(), 1)
+        pairs = np.full(total, -1, dtype=np.int32)
+        fit = np.zeros(total)
+        _check(self.ctx, L.bhip_assoc_l2_surf(self._h, len(a), a.ctypes.data_as(_lib._ip), b.ctypes.data_as(_lib._ip), float(maxError),
+                                              1 if backwardsValidation else 0, pairs.ctypes.data_as(_lib._ip), fit.ctypes.data_as(_lib._dp)))
+        return pairs, fit
+
     def totalFeatures(self):
         n = C.c_longlong(0)
         _check(self.ctx, _lib.load().bhip_surf_total(self._h, C.byref(n)))

@@ -645,6 +645,34 @@ int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, ui
 	return BHIP_OK;
 }
 
+// the whole batch of the last detect in ONE set of copies (per-image slices start at the exclusive prefix of bhip_surf_count):
+// what a batched caller (DetectDescribeSurfHip.detectBatch) uses instead of `batch` bhip_surf_fetch calls
+int bhip_surf_fetch_all(bhip_surf* s, double* xy_scale, double* angle, uint8_t* white, double* desc) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->haveResult) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result");
+	const long long total = s->det.total;
+	if (total == 0) return BHIP_OK;
+	const int dof = s->dofOut();
+	if (xy_scale) {
+		// key points sit in [image][cap] KeyPoint records: pack x, y, scale of every image into the compact layout on the device first
+		BHIP_TRY(s->xysBuf.reserve(ctx, (size_t)total * 24));
+		for (int i = 0; i < s->batch; i++) {
+			const int n = s->det.counts[i];
+			if (n > 0)
+				BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->xysBuf.p + (size_t)s->starts[i] * 24, 24, s->det.sorted.as<KeyPoint>() + (long long)i * s->det.cap,
+											   sizeof(KeyPoint), 24, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+		}
+		BHIP_HIP(ctx, hipMemcpyAsync(xy_scale, s->xysBuf.p, (size_t)total * 24, hipMemcpyDeviceToHost, ctx->stream));
+	}
+	if (angle) BHIP_HIP(ctx, hipMemcpyAsync(angle, s->angBuf.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+	if (white) BHIP_HIP(ctx, hipMemcpyAsync(white, s->whiteBuf.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+	if (desc) BHIP_HIP(ctx, hipMemcpyAsync(desc, s->descBuf.p, (size_t)total * 8 * dof, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
 int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const double** dev_xy_scale, const uint8_t** dev_white, int* n) {
 	if (!s) return BHIP_ERR_INVALID;
 	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
@@ -962,6 +990,42 @@ int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double
 		BHIP_TRY(assocL2Exact(ctx, dev_src + srcOff[p] * dof, ns[p], dev_dst + dstOff[p] * dof, nd[p], dof, maxErr, backwards, 0, dev_pairs + srcOff[p],
 							  dev_fit + srcOff[p]));
 	}
+	return BHIP_OK;
+}
+
+
+// AssociateDescription over descriptors that are still resident from the last detect of `s` (FastQueue<BrightFeature> lists a provider
+// recognises as its own): problem p associates image srcImage[p] (source) with image dstImage[p] (destination) -- same rules as
+// bhip_assoc_l2_f64, no descriptor upload.  pairs / fit are host arrays over the compact key-point index space of the batch: the results
+// of problem p start at the exclusive prefix of the counts of srcImage[p] (every image may be a source at most once per call).
+int bhip_assoc_l2_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->haveResult) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result");
+	if (count < 0 || (count > 0 && (!srcImage || !dstImage || !pairs || !fit))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad problem table");
+	if (count == 0) return BHIP_OK;
+	const long long total = s->det.total;
+	std::vector<long long> so(count), doff(count);
+	std::vector<int> ns(count), nd(count);
+	std::vector<char> used(s->batch, 0);
+	for (int p = 0; p < count; p++) {
+		const int a = srcImage[p], b = dstImage[p];
+		if (a < 0 || a >= s->batch || b < 0 || b >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "image index outside the last batch");
+		if (used[a]) return bhip_fail(ctx, BHIP_ERR_INVALID, "an image may be the source of one problem per call");
+		used[a] = 1;
+		so[p] = s->starts[a]; ns[p] = s->det.counts[a];
+		doff[p] = s->starts[b]; nd[p] = s->det.counts[b];
+	}
+	if (total == 0) return BHIP_OK;
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)total * 4));
+	BHIP_TRY(sc->e.reserve(ctx, (size_t)total * 8));
+	BHIP_TRY(bhip_assoc_l2_dev_batched(ctx, s->descBuf.as<double>(), s->descBuf.as<double>(), s->dofOut(), count, so.data(), ns.data(), doff.data(), nd.data(),
+									   maxErr, backwards, sc->c.as<int>(), sc->e.as<double>()));
+	BHIP_HIP(ctx, hipMemcpyAsync(pairs, sc->c.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(fit, sc->e.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;
 }
 

@@ -258,8 +258,10 @@ __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 	const int yEnd = min(y0 + CS_ROWS, P.height);
 	// interior pixels only: the border columns (normalised forms) are written afterwards by the general kernel (borderOnly launch)
 	const bool allInterior = x >= R && x + 3 < P.width - R;
-	// two row buffers take turns: while row y is filtered and stored, the chunks of rows y+1 and y+2 are in flight
-	float4 bufA[NL], bufB[NL];
+	// NB row buffers take turns: while row y is filtered and stored, the chunks of the next NB - 1 rows are in flight (a wave has to keep
+	// several KB on the way to cover the HBM latency at 8 waves per SIMD)
+	constexpr int NB = KW <= 5 ? 4 : (KW <= 7 ? 3 : 2);
+	float4 buf[NB][NL];
 	auto fetch = [&](float4 (&buf)[NL], int y) {
 		if (y < yEnd) {
 			const float* row = img + (long long)y * P.inStride;
@@ -288,23 +290,25 @@ __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 				if (x + j >= R && x + j < P.width - R) dst[j] = r[j];
 		}
 	};
-	fetch(bufA, y0);
-	fetch(bufB, y0 + 1);
-	for (int y = y0; y < yEnd; y += 2) {
-		emit(bufA, y);
-		fetch(bufA, y + 2);
-		emit(bufB, y + 1);
-		fetch(bufB, y + 3);
+#pragma unroll
+	for (int q = 0; q < NB; q++) fetch(buf[q], y0 + q);
+	for (int y = y0; y < yEnd; y += NB) {
+#pragma unroll
+		for (int q = 0; q < NB; q++) {
+			emit(buf[q], y + q);
+			fetch(buf[q], y + q + NB);
+		}
 	}
 }
 
 // Vertical: lane l owns columns 4l..4l+3 and walks a strip of CS_ROWS_V output rows with the KW input rows of the current output in a
-// register ring of KW+2 slots (the two extra slots receive the rows of the next two outputs while the current one is computed).  Strips that touch the top or
+// register ring of KW+PF slots (the extra slots receive the rows of the next PF outputs while the current one is computed).  Strips that touch the top or
 // bottom border evaluate the border rules per row from the same ring.
 #define CS_ROWS_V 32
 template <int KW>
 __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
-	constexpr int R = KW / 2, RING = KW + 2;
+	constexpr int PF = KW <= 5 ? 3 : 2;        // rows requested ahead of the output being computed
+	constexpr int R = KW / 2, RING = KW + PF;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int x = blockIdx.x * 256 + 4 * lane;
 	const int y0 = (blockIdx.y * 4 + wave) * CS_ROWS_V;
@@ -320,13 +324,13 @@ __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
 	float4 ring[RING];
 	// ring[(t + i) % RING] = input row y0 - R + t + i, the tap i of output row y0 + t
 #pragma unroll
-	for (int i = 0; i < KW + 1; i++) ring[i] = loadRow(y0 - R + i);
+	for (int i = 0; i < KW + PF - 1; i++) ring[i] = loadRow(y0 - R + i);
 	for (int tb = 0; y0 + tb < yEnd; tb += RING) {
 #pragma unroll
 		for (int j = 0; j < RING; j++) {
 			const int y = y0 + tb + j;
 			if (y < yEnd) {
-				if (y + 2 < yEnd) ring[(j + KW + 1) % RING] = loadRow(y + 2 + R);   // a spare slot receives the last tap of the output after next
+				if (y + PF < yEnd) ring[(j + KW + PF - 1) % RING] = loadRow(y + PF + R);   // a spare slot receives the last tap of the output PF rows on
 				float r[4];
 				const float4 t0 = ring[j % RING];
 				r[0] = t0.x * P.k[0]; r[1] = t0.y * P.k[0]; r[2] = t0.z * P.k[0]; r[3] = t0.w * P.k[0];

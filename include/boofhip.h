@@ -125,6 +125,15 @@ int bhip_surf_count(bhip_surf* s, int image, int* n);
 /* getLocation(i)/scale -> xy_scale[3n] ; getOrientation(i) -> angle[n] ; BrightFeature.white -> white[n] ;
  * getDescription(i).value -> desc[64n].  getRadius(i) = scale*2 (BoofDefaults.SURF_SCALE_TO_RADIUS).  Any pointer may be NULL. */
 int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, uint8_t* white, double* desc);
+/* the same for the WHOLE batch of the last detect in one set of copies: image i's slice starts at the exclusive prefix of the counts
+ * (key point k of image i at index sum(count[0..i)) + k); arrays sized with bhip_surf_total */
+int bhip_surf_fetch_all(bhip_surf* s, double* xy_scale, double* angle, uint8_t* white, double* desc);
+/* AssociateDescription.associate() on descriptor lists that are still resident from the last detect of `s` (F:abst/feature/associate/
+ * AssociateDescription.java:42-61 with lists a provider recognises as its own getDescription() objects): problem p associates image
+ * srcImage[p] (source) with image dstImage[p] (destination), ScoreAssociateEuclideanSq_F64, same rules and results as bhip_assoc_l2_f64, no
+ * descriptor upload.  pairs / fit: host arrays of bhip_surf_total entries; problem p's results start at the exclusive prefix of the counts
+ * of srcImage[p] (an image may be the source of one problem per call); entries of images that are no source are unspecified. */
+int bhip_assoc_l2_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit);
 /* device views of the same results (valid until the next detect): descriptors [n][dof] doubles, laplacian signs [n] bytes */
 int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const double** dev_xy_scale, const uint8_t** dev_white, int* n);
 int bhip_surf_dof(bhip_surf* s);

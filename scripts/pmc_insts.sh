@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_insts && mkdir -p gpurun_out/pmc_insts
 echo "pmc insts: $(date +%T)"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_insts -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --batch 32 > gpurun_out/pmc_insts/run.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_insts -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > gpurun_out/pmc_insts/run.log 2>&1
 python3 - > gpurun_out/pmc_insts/summary.txt <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float))

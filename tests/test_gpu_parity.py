@@ -1165,3 +1165,31 @@ def test_device_batched_ip_ops(api, orc, w, h, B):
         for b in range(B):
             if counts[b]:
                 assert np.array_equal(words[start[b]:start[b + 1]], orc.brief_describe(frames[b], pts[start[b]:start[b + 1]], 16, sp, cp)), b
+
+
+def test_batch_level_fetch_and_resident_association(api, orc):
+    """bhip_surf_fetch_all == the per-image bhip_surf_fetch slices; bhip_assoc_l2_surf (descriptors still resident from the detect) ==
+    bhip_assoc_l2_f64 on the fetched descriptors == the oracle's greedy association, pairs and scores identical."""
+    frames = [orc.noise_image(200, 150, 40 + i) for i in range(4)] + [orc.Gray(200, 150)]   # the last frame is blank: no key points
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32)
+    dd.detectBatch([G(api, f) for f in frames])
+    xys, ang, white, desc, starts = dd.fetchAll()
+    assert starts[-1] == dd.totalFeatures() and starts[-1] == starts[-2]
+    for i in range(len(frames)):
+        one = dd._results(i)
+        sl = slice(int(starts[i]), int(starts[i + 1]))
+        assert np.array_equal(xys[sl], one[0]) and np.array_equal(ang[sl], one[1]) and np.array_equal(white[sl], one[2]) and np.array_equal(desc[sl], one[3])
+    src = np.array([0, 1, 2, 3, 4], np.int32)
+    dst = np.array([1, 2, 3, 4, 0], np.int32)
+    for backwards in (True, False):
+        for maxErr in (api.Double_MAX_VALUE, 0.2):
+            pairs, fit = dd.associateImages(src, dst, maxErr, backwards)
+            for a, b in zip(src, dst):
+                sa = slice(int(starts[a]), int(starts[a + 1]))
+                db = desc[int(starts[b]):int(starts[b + 1])]
+                ep, ef = orc.associate_l2(desc[sa], db, maxErr, backwards)
+                assert np.array_equal(pairs[sa], ep) and np.array_equal(fit[sa], ef), (a, b, backwards, maxErr)
+    with pytest.raises(api.IllegalArgumentException):
+        dd.associateImages([0, 0], [1, 2])       # an image may be the source of one problem per call
+    with pytest.raises(api.IllegalArgumentException):
+        dd.associateImages([0], [7])
