@@ -560,8 +560,10 @@ int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* start
 		const int st = stride ? stride[i] : width;
 		if (!img[i] || st < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
 		const float* src = img[i] + (startIndex ? startIndex[i] : 0);
-		BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width * 4, src, (size_t)st * 4, (size_t)width * 4, height,
-									   hipMemcpyHostToDevice, ctx->stream));
+		// a dense frame is one linear copy (the 2-D form is several times slower over PCIe even when pitch == width)
+		if (st == width) BHIP_HIP(ctx, hipMemcpyAsync((char*)s->inBuf.p + imgBytes * i, src, imgBytes, hipMemcpyHostToDevice, ctx->stream));
+		else BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width * 4, src, (size_t)st * 4, (size_t)width * 4, height,
+											hipMemcpyHostToDevice, ctx->stream));
 	}
 	ImgView in{s->inBuf.as<float>(), (long long)width * height, width, width, height};
 	return surfRun(s, in, batch);
@@ -601,8 +603,9 @@ int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* star
 	for (int i = 0; i < batch; i++) {
 		const int st = stride ? stride[i] : width;
 		if (!img[i] || st < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
-		BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width, img[i] + (startIndex ? startIndex[i] : 0), (size_t)st, (size_t)width, height,
-									   hipMemcpyHostToDevice, ctx->stream));
+		const uint8_t* src = img[i] + (startIndex ? startIndex[i] : 0);
+		if (st == width) BHIP_HIP(ctx, hipMemcpyAsync((char*)s->inBuf.p + imgBytes * i, src, imgBytes, hipMemcpyHostToDevice, ctx->stream));
+		else BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width, src, (size_t)st, (size_t)width, height, hipMemcpyHostToDevice, ctx->stream));
 	}
 	ImgView in{s->inBuf.as<float>(), (long long)width * height, width, width, height};   // only the pointer and the shape are used
 	return surfRun(s, in, batch, 0, true);
