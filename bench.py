@@ -41,6 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 INT8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec); the exact-fp64 association path is VALU, not MFMA
 PCIE_GBS = 63.0  # MI355X_MICROARCH.md: host link PCIe Gen5 x16 (spec)
+_T0 = time.perf_counter()
 MIN_TIMED_SECONDS = 3.0  # default --steps: enough steps for a timed region an external GPU-busy sampler can see
 
 
@@ -275,6 +276,13 @@ class HostBoundary:
         return sum(len(d) for d in self.desc)
 
 
+def trace(msg):
+    """progress line on stderr when BHIP_BENCH_TRACE is set (profiler runs: shows which stage a slow counter pass is in)"""
+    if os.environ.get("BHIP_BENCH_TRACE"):
+        sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def pmc_traffic(tag, batch, height, width):
     """HBM-side bytes per launch of kernel `tag` from the committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json, collected by
     scripts/pmc_traffic.sh on this workload and corrected as its header says); None when no summary matches the workload."""
@@ -390,14 +398,17 @@ def run_frames(args, D):
     B = args.batch or 256
     H = args.height or 1080
     W = args.width or 1920
+    trace("synthesising %d frames" % B)
     frames = synth_frames(B, H, W, 1000 + D.rank * B, D.device)
     torch.cuda.synchronize()
+    trace("frames resident")
     hp = HotPath(D.local_rank, B, H, W)
 
     kp = [0]
 
     def step():
         kp[0] = hp.step(frames)
+        trace("step done: %d key points" % kp[0])
         return kp[0]
 
     for _ in range(max(args.warmup, 0)):

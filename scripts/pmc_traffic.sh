@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_traffic && mkdir -p gpurun_out/pmc_traffic
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc pass $c: $(date +%T)"
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic/$c -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-end-to-end > gpurun_out/pmc_traffic/$c.log 2>&1 || exit 1
+  BHIP_BENCH_TRACE=1 timeout -k 10 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic/$c -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-end-to-end > gpurun_out/pmc_traffic/$c.log 2>&1 || exit 1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
