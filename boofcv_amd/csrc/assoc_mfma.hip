@@ -3,29 +3,38 @@
 // Reference: AssociateGreedy.associate  F:alg/feature/associate/AssociateGreedy.java:65-118 with
 //            DescriptorDistance.euclideanSq  F:alg/descriptor/DescriptorDistance.java:55-64  (SURVEY hard part 3)
 //
-// The N x M x 64 contraction runs on the matrix cores in fp32 (v_mfma_f32_32x32x2_f32, exact f32 fma chain):
-//     d~(i,j) = |a_i|^2 + |b_j|^2 - 2 <fl32(a_i), fl32(b_j)>
-// with the rigorous bound |d~ - d| <= eps(i,j) = 71 u (|a_i|^2 + |b_j|^2), u = 2^-24
-//   (input rounding 2u|a||b|, 64-term fma chain 64u|a||b|, both doubled by the factor 2, |a||b| <= (|a|^2+|b|^2)/2, epilogue <= 4u(|a|^2+|b|^2)).
-// Pass 1 reduces d~ to per-row and per-column minima.  Pass 2 recomputes the tiles and lists every pair inside the band
-//     d~(i,j) <= rowmin~(i) + band(i)   /   d~(i,j) <= colmin~(j) + band(j),     band = 2 * 160 u (|.|^2 + max|.|^2)  (> 2 eps)
-// The true row arg-min (and every exact tie of it) and the true column minimum (and every exact tie) are provably inside those
-// lists, and everything outside is strictly larger than the list's best.  The listed pairs (about one per row/column) are then
-// re-scored with the exact sequential fp64 loop and the reference's rules are applied to the exact values:
+// The matrix cores only FILTER: they find, for every row and every column, the short list of pairs that can attain the exact minimum; the
+// listed pairs (about 1.15 per row / column on SURF descriptors) are then re-scored with the reference's sequential fp64 loop and the
+// reference's rules are applied to those exact values.  Because the filter only needs a rigorous error bound, not accuracy, it runs in
+// fp16 (v_mfma_f32_32x32x16_f16, 16x the fp32 matrix rate) on descriptors scaled by one power of two 2^-q per call so that the largest
+// squared norm lies in [1/4, 1):
+//     a^ = fl16(2^-q a),  n_a = |2^-q a|^2 (fp32, rounded up) = hi + lo (two fp16),
+//     d~(i,j) = n_a + n_b - 2 <a^_i, b^_j>     -- ONE K = 80 contraction: the row holds [-2 a^ | hi lo 1 1 | 0...], the column [b^ | 1 1 hi lo | 0...]
+// Error bound (u = 2^-11, s = 2^-25 fp16 subnormal half-spacing, |a'|,|b'| < 1 after scaling; products of fp16 are exact in fp32):
+//     input rounding   2[(2u + u^2)|a'||b'| + 8s(1+u)(|a'|+|b'|) + 64 s^2]   <= 9.78e-4 (n_a + n_b) + 1e-6     (double rounding f64->f32->f16: + 2^-24 rel.)
+//     norm split       2^-22 (n_a + n_b) + 2^-24 ;  norm round-up 4 * 2^-24 (n_a + n_b)
+//     fp32 accumulate  85 additions, <= 2^-23 relative each even if truncating: 2^-16 (n_a + n_b + 2|a'||b'|) <= 2^-15 (n_a + n_b)
+//   =>  |d~ - d'| <= eps(i,j) = C16 (n_a + n_b) + ABS16,   C16 = 1.03e-3,  ABS16 = 2e-6   (d' = 2^-2q d, the exact scaled distance)
+// Pass 1 reduces d~ to per-row and per-column minima.  Pass 2 recomputes the tiles (same instructions, same bits) and lists every pair with
+//     d~(i,j) <= rowmin~(i) + band(i)   /   d~(i,j) <= colmin~(j) + band(j),     band = 2 (C16 (n + max n) + ABS16)   (>= 2 eps)
+// The true row arg-min (and every exact tie of it) and the true column minimum (and every exact tie) are provably inside those lists and
+// everything outside is strictly larger than the list's best.  Exact re-score + the reference's rules:
 //   forward : smallest exact score, largest destination index among exact ties, inclusive maxFitError
 //   backward: (i -> m) survives iff i is the only row attaining the exact minimum of column m
-// Degenerate inputs (candidate list overflow, e.g. all descriptors equal; non-finite values) fall back to the exact VALU kernels.
+// Degenerate inputs (candidate list overflow, e.g. many near-equal descriptors; non-finite values) fall back to the exact VALU kernels.
 //
-// Layout: descriptors are converted once per call to fp32 rows [row][64]; lane l of a wave holds k in [32(l>>5), 32(l>>5)+32) of row/col
-// (l&31), which is exactly the A / B fragment order of 32 consecutive 32x32x2 MFMAs -- operands stay in VGPRs, no LDS.
-// Each wave owns 32 source rows and sweeps destination columns 64 at a time (two accumulators).
-// Bound: MFMA (fp32 matrix rate, 157 TFLOP/s); algorithmic flops per pass = 2 * Ns * Nd * 64.
+// Layout: one 144-byte row per descriptor = 9 chunks of 8 halves (64 values + [hi lo 1 1 0 0 0 0]).  A wave owns 64 source rows (two A
+// tiles, operands in VGPRs for the whole sweep) and sweeps destination columns 64 at a time (two B tiles staged once per block in LDS,
+// double buffered): 20 MFMAs per step, every B fragment read from LDS feeds two of them.  The norms ride in the contraction, so the
+// epilogue is one v_min3 per two scores (pass 1) or one compare per score (pass 2).
+// Bound: MFMA (fp16 matrix rate); algorithmic flops per pass = 2 * Ns * Nd * 64.
 #include "common.h"
 #include <cfloat>
+#include <cmath>
 #include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 struct AssocProblem {
 	int srcOff, ns, dstOff, nd;   // rows in the src / dst descriptor buffers
@@ -39,8 +48,19 @@ struct AssocCand {
 	double score;
 };
 
-#define BAND_C 160.0f
-#define U24 5.9604644775390625e-08f
+#define C16 1.03e-3f
+#define ABS16 2.0e-6f
+#define BIG16 60000.0f     // "norm" of a row / column that does not exist: its scores can never pass a threshold (real norms are < 1)
+#define ROW_CHUNKS 9       // uint4 per stored row
+#define BLOCK_ROWS 256     // 4 waves x 64 rows
+#define COL_CAP 4096       // columns one block sweeps at most (its column minima live in LDS)
+
+// LDS writes of one lane visible to the other lanes of the same wave (lock-step wave: only the memory counter has to drain)
+__device__ __forceinline__ void waveSyncLds() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ unsigned int fkey(float f) {
 	const unsigned int b = __float_as_uint(f);
@@ -49,26 +69,55 @@ __device__ __forceinline__ unsigned int fkey(float f) {
 __device__ __forceinline__ float fkeyInv(unsigned int k) {
 	return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
+// q with max norm * 2^-2q in [1/4, 1)  (0 when there is no positive norm)
+__device__ __forceinline__ int scaleExp(float maxN) {
+	if (!(maxN > 0.0f)) return 0;
+	int e;
+	(void)frexpf(maxN, &e);
+	return (e + 1) >> 1;
+}
 
-// ---- fp64 -> fp32 rows + squared norms; flags[0] = non-finite seen, flags[1] = max norm (float bits, non-negative) ----
-__global__ __launch_bounds__(256) void k_assoc_prep(const double* __restrict__ D, long long rows, float* __restrict__ F, float* __restrict__ nrm,
-													  int* __restrict__ flags) {
-	const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (row >= rows) return;
-	const double v = D[row * 64 + lane];
-	F[row * 64 + lane] = (float)v;
-	double s = v * v;
+// ---- squared norms (fp32, rounded up); flags[0] = non-finite seen, flags[1] = max norm (float bits, non-negative) ----
+// 16 lanes per row, 4 consecutive values (two 16-byte loads) per lane
+__global__ __launch_bounds__(256) void k_assoc_norms(const double* __restrict__ D, long long rows, float* __restrict__ nrm, int* __restrict__ flags) {
+	const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+	const int part = threadIdx.x & 15;
+	if (row >= rows) return;   // whole 16-lane groups leave together
+	const double2* src = (const double2*)(D + row * 64 + 4 * part);
+	const double2 v0 = src[0], v1 = src[1];
+	double s = (v0.x * v0.x + v0.y * v0.y) + (v1.x * v1.x + v1.y * v1.y);
 #pragma unroll
-	for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-	if (lane == 0) {
+	for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+	if (part == 0) {
 		const float n = (float)s;
-		// round the norm up so the band computed from it can only grow
-		const float nUp = n * (1.0f + 4.0f * U24);
+		const float nUp = n * (1.0f + 4.0f * 5.9604644775390625e-08f);   // rounded up: a band computed from it can only grow
 		nrm[row] = nUp;
 		// one hot word for the whole launch: only touch it when this row actually raises the maximum (a handful of times per launch)
 		if (!(s < 1e30)) atomicOr(&flags[0], 1);  // NaN, Inf or absurdly large: use the exact path
 		else if (__float_as_int(nUp) > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[1], __float_as_int(nUp));
+	}
+}
+
+// ---- fp64 -> scaled fp16 rows [64 values | hi lo 1 1 0 0 0 0]; nrm is rescaled in place ----
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_assoc_half(const double* __restrict__ D, long long rows, float* __restrict__ nrm, const int* __restrict__ flags,
+													  _Float16* __restrict__ Hrow) {
+	const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+	const int part = threadIdx.x & 15;
+	if (row >= rows) return;
+	const int q = scaleExp(__int_as_float(flags[1]));
+	const double2* src = (const double2*)(D + row * 64 + 4 * part);
+	const double2 v0 = src[0], v1 = src[1];
+	_Float16* out = Hrow + row * (ROW_CHUNKS * 8);
+	const h16x4 hv = {(_Float16)(float)ldexp(v0.x, -q), (_Float16)(float)ldexp(v0.y, -q), (_Float16)(float)ldexp(v1.x, -q), (_Float16)(float)ldexp(v1.y, -q)};
+	*(h16x4*)(out + 4 * part) = hv;
+	if (part == 0) {
+		const float n = ldexpf(nrm[row], -2 * q);
+		const _Float16 hi = (_Float16)n;
+		const _Float16 lo = (_Float16)(n - (float)hi);
+		const h16x8 e = {hi, lo, (_Float16)1.0f, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+		*(h16x8*)(out + 64) = e;
+		nrm[row] = n;
 	}
 }
 
@@ -77,140 +126,162 @@ __global__ void k_fill_u32(unsigned int* p, long long n, unsigned int v) {
 	if (i < n) p[i] = v;
 }
 
-// thr = min~ + band, band = 2 * 160 u (norm + maxNorm)
+// thr = min~ + band, band = 2 (C16 (norm + maxNorm) + ABS16), scaled units
 __global__ void k_assoc_thresholds(const AssocProblem* __restrict__ probs, int count, const float* __restrict__ nrmS, const float* __restrict__ nrmD,
 								   const unsigned int* __restrict__ rowKey, const unsigned int* __restrict__ colKey, const int* __restrict__ flags,
 								   float* __restrict__ rowThr, float* __restrict__ colThr) {
 	const int p = blockIdx.y;
 	const AssocProblem P = probs[p];
-	const float maxN = __int_as_float(flags[1]);
+	const float maxRaw = __int_as_float(flags[1]);
+	const float maxN = ldexpf(maxRaw, -2 * scaleExp(maxRaw));
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.ns + P.nd; i += gridDim.x * blockDim.x) {
 		if (i < P.ns) {
-			const float band = 2.0f * BAND_C * U24 * (nrmS[P.srcOff + i] + maxN);
+			const float band = 2.0f * (C16 * (nrmS[P.srcOff + i] + maxN) + ABS16);
 			rowThr[P.rowBase + i] = fkeyInv(rowKey[P.rowBase + i]) + band;
 		} else {
 			const int j = i - P.ns;
-			const float band = 2.0f * BAND_C * U24 * (nrmD[P.dstOff + j] + maxN);
+			const float band = 2.0f * (C16 * (nrmD[P.dstOff + j] + maxN) + ABS16);
 			colThr[P.colBase + j] = fkeyInv(colKey[P.colBase + j]) + band;
 		}
 	}
 }
 
 struct MfmaArgs {
-	const float* Fs;
-	const float* Fd;
-	const float* nrmS;
-	const float* nrmD;
+	const uint4* Hs;   // 9 chunks per row
+	const uint4* Hd;
 	const AssocProblem* probs;
 	const AssocBlock* blocks;
 	unsigned int* rowKey;
 	unsigned int* colKey;
 	const float* rowThr;
 	const float* colThr;
-	AssocCand* rowCand;
-	AssocCand* colCand;
-	int* counters;   // [0] row candidates, [1] column candidates
+	AssocCand* cand;
+	int* counter;    // number of listed pairs
 	int cap;
 };
 
-#define CAND_BUF 96   // per-wave, per-list staging slots in LDS (>= 64: one ballot can add up to 64 entries)
+#define CAND_LDS 512   // per-wave staging slots in LDS; a 64-row strip lists about 150 pairs per sweep
 
-// Wave-aggregated candidate lists: hits are staged in LDS and flushed with ONE atomicAdd per flush, so the two global counters see a
-// few atomics per wave instead of one per candidate (a single contended word sustains only ~88 atomics/us, MI355X_MICROARCH.md).
-struct CandStage {
-	int4* buf;       // this wave's [2][CAND_BUF]
-	int cnt[2];      // wave-uniform
-};
-__device__ __forceinline__ void candFlush(const MfmaArgs& A, CandStage& S, int list, int lane) {
-	const int n = S.cnt[list];
-	if (n == 0) return;
-	int base = 0;
-	if (lane == 0) base = atomicAdd(&A.counters[list], n);
-	base = __builtin_amdgcn_readfirstlane(base);
-	AssocCand* out = list == 0 ? A.rowCand : A.colCand;
-	for (int k = lane; k < n; k += 64) {
-		if (base + k < A.cap) {
-			const int4 v = S.buf[list * CAND_BUF + k];
-			AssocCand c; c.p = v.x; c.i = v.y; c.j = v.z; c.pad = 0; c.score = 0;
-			out[base + k] = c;
+// One list for both directions: a pair listed for its row also updates its column's exact minimum and vice versa, which is harmless (every
+// listed pair is a real pair, and every pair that can attain a row / column minimum is listed).  Hits are rare per lane, so a hit lane
+// appends with one LDS atomic; the wave flushes its staging area once, with ONE atomicAdd on the global counter (a single contended word
+// sustains only ~88 atomics/us, MI355X_MICROARCH.md).  Entries that do not fit the staging area go to the global list directly.
+// (kept out of line: inlined at the 32 accumulator registers of the hot loop it costs the kernel its register budget)
+__device__ __noinline__ void candAdd(AssocCand* cand, int* counter, int cap, int2* buf, int* cnt, int bits, int p, int rr, int colA, int colB) {
+#pragma unroll 1
+	for (int k = 0; k < 2; k++) {
+		if ((bits >> k) & 1) {
+			const int col = k ? colB : colA;
+			const int pos = atomicAdd(cnt, 1);
+			if (pos < CAND_LDS) {
+				buf[pos] = make_int2(rr, col);
+			} else {
+				const int g = atomicAdd(counter, 1);
+				if (g < cap) { AssocCand c; c.p = p; c.i = rr; c.j = col; c.pad = 0; c.score = 0; cand[g] = c; }
+			}
 		}
 	}
-	S.cnt[list] = 0;
 }
-__device__ __forceinline__ void candPush(const MfmaArgs& A, CandStage& S, int list, bool cond, int p, int i, int j, int lane) {
-	const unsigned long long m = __ballot(cond);
-	if (m == 0) return;
-	const int n = __popcll(m);
-	if (S.cnt[list] + n > CAND_BUF) candFlush(A, S, list, lane);
-	if (cond) {
-		const int pos = S.cnt[list] + __popcll(m & ((1ull << lane) - 1ull));
-		S.buf[list * CAND_BUF + pos] = make_int4(p, i, j, 0);
+__device__ __forceinline__ void candFlush(const MfmaArgs& A, const int2* buf, const int* cnt, int p, int lane) {
+	waveSyncLds();
+	const int n = min(*cnt, CAND_LDS);
+	if (n == 0) return;
+	int base = 0;
+	if (lane == 0) base = atomicAdd(A.counter, n);
+	base = __builtin_amdgcn_readfirstlane(base);
+	for (int k = lane; k < n; k += 64) {
+		if (base + k < A.cap) {
+			const int2 v = buf[k];
+			AssocCand c; c.p = p; c.i = v.x; c.j = v.y; c.pad = 0; c.score = 0;
+			A.cand[base + k] = c;
+		}
 	}
-	S.cnt[list] += n;
+}
+
+__device__ __forceinline__ h16x8 asHalf8(uint4 v) { return __builtin_bit_cast(h16x8, v); }
+__device__ __forceinline__ uint4 extChunk(float n0, float n1, float n2, float n3) {   // [n0 n1 n2 n3 0 0 0 0] as halves
+	const h16x8 h = {(_Float16)n0, (_Float16)n1, (_Float16)n2, (_Float16)n3, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+	return __builtin_bit_cast(uint4, h);
 }
 
 template <int PASS>
 __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
-	__shared__ int4 candLds[4][2 * CAND_BUF];
+	// B tiles: [buffer][tile][chunk * 33 + column]; chunk 8 = [1 1 hi lo 0..], chunk 9 = zeros (k = 72..79, read by the upper half-wave)
+	__shared__ uint4 tileB[2][2][10 * 33];
+	__shared__ unsigned int colMin[PASS == 1 ? COL_CAP : 1];
+	__shared__ int2 candLds[PASS == 2 ? 4 : 1][PASS == 2 ? CAND_LDS : 1];
+	__shared__ int candCnt[4];
 	const AssocBlock B = A.blocks[blockIdx.x];
+	if (B.col0 >= B.col1) return;   // padding entry of the block table
 	const AssocProblem P = A.probs[B.p];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int r = lane & 31, h = lane >> 5;
-	const int rowT = B.row0 + 32 * wave;  // first row of this wave's tile
+	const int rowT = B.row0 + 64 * wave;  // first row of this wave's two tiles
 	const bool live = rowT < P.ns;        // a wave without rows still stages B tiles and meets the barriers
-	CandStage S;
-	S.buf = candLds[wave];
-	S.cnt[0] = 0;
-	S.cnt[1] = 0;
+	int2* candBuf = candLds[PASS == 2 ? wave : 0];
+	int* candN = &candCnt[wave];
+	if (lane == 0) *candN = 0;   // ordered before first use by the barrier after the first stash
 
-	// A fragment: row rowT + r, k in [32h, 32h+32)
-	float a[32];
-	{
-		const int row = rowT + r;
-		if (row < P.ns) {
-			const f32x4* src = (const f32x4*)(A.Fs + ((long long)(P.srcOff + row) * 64 + 32 * h));
+	if (tid < 128) tileB[tid >> 6][(tid >> 5) & 1][9 * 33 + (tid & 31)] = make_uint4(0, 0, 0, 0);
+	if (PASS == 1)
+		for (int c = tid; c < B.col1 - B.col0; c += 256) colMin[c] = 0xFFFFFFFFu;
+
+	// A fragments: tile t, row rowT + 32 t + r; MFMA s (k = 16 s + 8 h ..) reads chunk 2 s + h, the fifth reads chunk 8 / zeros
+	h16x8 a[2][5];
 #pragma unroll
-			for (int q = 0; q < 8; q++) {
-				const f32x4 v = src[q];
-				a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-			}
+	for (int t = 0; t < 2; t++) {
+		const int row = rowT + 32 * t + r;
+		if (row < P.ns) {
+			const uint4* src = A.Hs + (long long)(P.srcOff + row) * ROW_CHUNKS;
+#pragma unroll
+			for (int s = 0; s < 4; s++) a[t][s] = asHalf8(src[2 * s + h]) * (_Float16)(-2.0f);
+			a[t][4] = asHalf8(h == 0 ? src[8] : make_uint4(0, 0, 0, 0));
 		} else {
 #pragma unroll
-			for (int q = 0; q < 32; q++) a[q] = 0.0f;
+			for (int s = 0; s < 4; s++) a[t][s] = asHalf8(make_uint4(0, 0, 0, 0));
+			a[t][4] = asHalf8(h == 0 ? extChunk(BIG16, 0.0f, 1.0f, 1.0f) : make_uint4(0, 0, 0, 0));
 		}
 	}
-	// per accumulator register: the row it belongs to (C layout: row = (reg&3) + 8*(reg>>2) + 4h, col = lane&31)
-	float rowN[16];   // |a|^2 of that row (INF when the row does not exist)
-	float rowV[16];   // PASS 1: running row minimum ; PASS 2: row threshold
+	// per accumulator register: C layout row = (reg&3) + 8*(reg>>2) + 4h of the tile, col = lane&31
+	float rowV[2][16];   // PASS 1: running row minimum ; PASS 2: row threshold
 #pragma unroll
-	for (int g = 0; g < 16; g++) {
-		const int rr = rowT + (g & 3) + 8 * (g >> 2) + 4 * h;
-		const bool ok = rr < P.ns;
-		rowN[g] = ok ? A.nrmS[P.srcOff + rr] : INFINITY;
-		if (PASS == 1) rowV[g] = INFINITY;
-		else rowV[g] = ok ? A.rowThr[P.rowBase + rr] : -INFINITY;
-	}
+	for (int t = 0; t < 2; t++)
+#pragma unroll
+		for (int g = 0; g < 16; g++) {
+			const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+			if (PASS == 1) rowV[t][g] = INFINITY;
+			else rowV[t][g] = rr < P.ns ? A.rowThr[P.rowBase + rr] : -INFINITY;
+		}
 
-	// The four waves of a block sweep the same destination columns, so every 64-column step of B is staged ONCE per block in LDS
-	// (fp32 rows as 16-byte chunks, [tile][chunk][column] with a pitch of 33 chunks: fragment reads are contiguous across lanes) and
-	// double-buffered: the next step's chunks are fetched into registers before this step's MFMAs and stored after them.  One L2 read
-	// of B per block instead of four, and its latency sits behind the matrix work.
-	__shared__ uint4 tileB[2][2][16 * 33];
-	const int tid = threadIdx.x;
-	uint4 pre[4];
+	// staging: 64 columns x 9 chunks per step, consecutive threads fetch consecutive 16-byte chunks of a row
+	uint4 pre[3];
 	auto fetch = [&](int c0) {
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const int g = tid + 256 * q;          // 2 tiles x 32 columns x 16 chunks
-			const int col = c0 + (g >> 4);        // (g >> 9) * 32 + ((g & 511) >> 4) == g >> 4
-			pre[q] = col < B.col1 ? ((const uint4*)(A.Fd + (long long)(P.dstOff + col) * 64))[g & 15] : make_uint4(0, 0, 0, 0);
+		for (int q = 0; q < 3; q++) {
+			const int g = tid + 256 * q;
+			if (g < 64 * ROW_CHUNKS) {
+				const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
+				const int col = c0 + cl;
+				uint4 v;
+				if (col < B.col1) {
+					v = A.Hd[(long long)(P.dstOff + col) * ROW_CHUNKS + ch];
+					if (ch == 8) { const unsigned int x = v.x; v.x = v.y; v.y = x; }   // [hi lo | 1 1] -> [1 1 | hi lo]
+				} else {
+					v = ch == 8 ? extChunk(1.0f, 1.0f, BIG16, 0.0f) : make_uint4(0, 0, 0, 0);
+				}
+				pre[q] = v;
+			}
 		}
 	};
 	auto stash = [&](int buf) {
 #pragma unroll
-		for (int q = 0; q < 4; q++) {
+		for (int q = 0; q < 3; q++) {
 			const int g = tid + 256 * q;
-			tileB[buf][g >> 9][(g & 15) * 33 + ((g & 511) >> 4)] = pre[q];
+			if (g < 64 * ROW_CHUNKS) {
+				const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
+				tileB[buf][cl >> 5][ch * 33 + (cl & 31)] = pre[q];
+			}
 		}
 	};
 	fetch(B.col0);
@@ -222,100 +293,93 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 		const bool okA = colA < B.col1, okB = colB < B.col1;
 		const bool more = c0 + 64 < B.col1;   // block-uniform
 		if (more) fetch(c0 + 64);
-		const float nbA = okA ? A.nrmD[P.dstOff + colA] : INFINITY;
-		const float nbB = okB ? A.nrmD[P.dstOff + colB] : INFINITY;
-		f32x16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-		f32x16 acc1 = acc0;
-		// lane (r, h) needs k in [32h, 32h+32) of columns colA / colB = chunks 8h .. 8h+7; two halves keep 32 B registers live, not 64
+		float tA = -INFINITY, tB = -INFINITY;
+		if (PASS == 2 && live) {
+			if (okA) tA = A.colThr[P.colBase + colA];
+			if (okB) tB = A.colThr[P.colBase + colB];
+		}
+		f32x16 acc[2][2];
+		if (live) {
 #pragma unroll
-		for (int half = 0; half < 2; half++) {
-			float b0[16], b1[16];
+			for (int t = 0; t < 2; t++)
 #pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const uint4 v = tileB[buf][0][(8 * h + 4 * half + q) * 33 + r], w = tileB[buf][1][(8 * h + 4 * half + q) * 33 + r];
-				b0[4 * q] = __uint_as_float(v.x); b0[4 * q + 1] = __uint_as_float(v.y); b0[4 * q + 2] = __uint_as_float(v.z); b0[4 * q + 3] = __uint_as_float(v.w);
-				b1[4 * q] = __uint_as_float(w.x); b1[4 * q + 1] = __uint_as_float(w.y); b1[4 * q + 2] = __uint_as_float(w.z); b1[4 * q + 3] = __uint_as_float(w.w);
-			}
+				for (int c = 0; c < 2; c++)
 #pragma unroll
-			for (int s = 0; s < 16; s++) {
-				acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[16 * half + s], b0[s], acc0, 0, 0, 0);
-				acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[16 * half + s], b1[s], acc1, 0, 0, 0);
+					for (int g = 0; g < 16; g++) acc[t][c][g] = 0.0f;
+#pragma unroll
+			for (int s = 0; s < 5; s++) {
+				const int ch = s < 4 ? 2 * s + h : 8 + h;
+				const h16x8 b0 = asHalf8(tileB[buf][0][ch * 33 + r]);
+				const h16x8 b1 = asHalf8(tileB[buf][1][ch * 33 + r]);
+				acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b0, acc[0][0], 0, 0, 0);
+				acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b0, acc[1][0], 0, 0, 0);
+				acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b1, acc[0][1], 0, 0, 0);
+				acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b1, acc[1][1], 0, 0, 0);
 			}
 		}
 		if (more) stash(buf ^ 1);   // the other buffer was last read before the previous barrier
 		if (live) {
-		if (PASS == 1) {
-			float cA = INFINITY, cB = INFINITY;
+			if (PASS == 1) {
+				float cA = INFINITY, cB = INFINITY;
 #pragma unroll
-			for (int g = 0; g < 16; g++) {
-				const float dA = (rowN[g] + nbA) - 2.0f * acc0[g];
-				const float dB = (rowN[g] + nbB) - 2.0f * acc1[g];
-				rowV[g] = fminf(rowV[g], fminf(dA, dB));
-				cA = fminf(cA, dA);
-				cB = fminf(cB, dB);
-			}
-			cA = fminf(cA, __shfl_xor(cA, 32, 64));
-			cB = fminf(cB, __shfl_xor(cB, 32, 64));
-			if (h == 0) {
-				if (okA) atomicMin(&A.colKey[P.colBase + colA], fkey(cA));
-				if (okB) atomicMin(&A.colKey[P.colBase + colB], fkey(cB));
-			}
-		} else {
-			const float tA = okA ? A.colThr[P.colBase + colA] : -INFINITY;
-			const float tB = okB ? A.colThr[P.colBase + colB] : -INFINITY;
-			// hit bits first (branch-free), then the rare staging work only for registers that have a hit somewhere in the wave
-			unsigned int hits = 0;
+				for (int t = 0; t < 2; t++)
 #pragma unroll
-			for (int g = 0; g < 16; g++) {
-				const float dA = (rowN[g] + nbA) - 2.0f * acc0[g];
-				const float dB = (rowN[g] + nbB) - 2.0f * acc1[g];
-				hits |= (dA <= rowV[g] || dB <= rowV[g] || dA <= tA || dB <= tB) ? (1u << g) : 0u;
-			}
-			unsigned int any = hits;
-#pragma unroll
-			for (int o = 32; o >= 1; o >>= 1) any |= __shfl_xor(any, o, 64);
-			any = __builtin_amdgcn_readfirstlane(any);
-#pragma unroll
-			for (int g = 0; g < 16; g++) {
-				if (any & (1u << g)) {
-					const int rr = rowT + (g & 3) + 8 * (g >> 2) + 4 * h;
-					const float dA = (rowN[g] + nbA) - 2.0f * acc0[g];   // same expression as above: identical bits
-					const float dB = (rowN[g] + nbB) - 2.0f * acc1[g];
-					candPush(A, S, 0, dA <= rowV[g], B.p, rr, colA, lane);
-					candPush(A, S, 0, dB <= rowV[g], B.p, rr, colB, lane);
-					candPush(A, S, 1, dA <= tA, B.p, rr, colA, lane);
-					candPush(A, S, 1, dB <= tB, B.p, rr, colB, lane);
+					for (int g = 0; g < 16; g++) {
+						rowV[t][g] = fminf(rowV[t][g], fminf(acc[t][0][g], acc[t][1][g]));
+						cA = fminf(cA, acc[t][0][g]);
+						cB = fminf(cB, acc[t][1][g]);
+					}
+				cA = fminf(cA, __shfl_xor(cA, 32, 64));
+				cB = fminf(cB, __shfl_xor(cB, 32, 64));
+				if (h == 0) {
+					if (okA) atomicMin(&colMin[colA - B.col0], fkey(cA));
+					if (okB) atomicMin(&colMin[colB - B.col0], fkey(cB));
 				}
+			} else {
+#pragma unroll
+				for (int t = 0; t < 2; t++)
+#pragma unroll
+					for (int g = 0; g < 16; g++) {
+						const float dA = acc[t][0][g], dB = acc[t][1][g];
+						const bool rA = dA <= rowV[t][g], rB = dB <= rowV[t][g], qA = dA <= tA, qB = dB <= tB;
+						if (__ballot(rA || rB || qA || qB) != 0ull) {   // wave-uniform, a few times per step
+							const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+							candAdd(A.cand, A.counter, A.cap, candBuf, candN, ((rA || qA) ? 1 : 0) | ((rB || qB) ? 2 : 0), B.p, rr, colA, colB);
+						}
+					}
 			}
 		}
-		}   // live
 		__syncthreads();
+	}
+	if (PASS == 1) {
+		// column minima of this block's rows -> global (one atomic per column per block); the last loop barrier ordered the LDS atomics
+		for (int c = tid; c < B.col1 - B.col0; c += 256) atomicMin(&A.colKey[P.colBase + B.col0 + c], colMin[c]);
 	}
 	if (!live) return;
 	if (PASS == 2) {
-		candFlush(A, S, 0, lane);
-		candFlush(A, S, 1, lane);
+		candFlush(A, candBuf, candN, B.p, lane);
 	}
 	if (PASS == 1) {
 #pragma unroll
-		for (int g = 0; g < 16; g++) {
-			float v = rowV[g];
+		for (int t = 0; t < 2; t++)
 #pragma unroll
-			for (int o = 16; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-			const int rr = rowT + (g & 3) + 8 * (g >> 2) + 4 * h;
-			if (r == 0 && rr < P.ns) atomicMin(&A.rowKey[P.rowBase + rr], fkey(v));
-		}
+			for (int g = 0; g < 16; g++) {
+				float v = rowV[t][g];
+#pragma unroll
+				for (int o = 16; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+				const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+				if (r == 0 && rr < P.ns) atomicMin(&A.rowKey[P.rowBase + rr], fkey(v));
+			}
 	}
 }
 
 // exact sequential fp64 score of every listed pair + exact minima per row / column (scores are >= 0: bit order == value order)
 __global__ __launch_bounds__(256) void k_assoc_exact(const double* __restrict__ src, const double* __restrict__ dst, const AssocProblem* __restrict__ probs,
-													   AssocCand* __restrict__ rowCand, AssocCand* __restrict__ colCand, const int* __restrict__ counters, int cap,
+													   AssocCand* __restrict__ cand, const int* __restrict__ counter, int cap,
 													   unsigned long long* __restrict__ rowBest, unsigned long long* __restrict__ colBest) {
-	const int nRow = min(counters[0], cap), nCol = min(counters[1], cap);
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nRow + nCol; t += gridDim.x * blockDim.x) {
-		const bool isRow = t < nRow;
-		AssocCand* c = isRow ? &rowCand[t] : &colCand[t - nRow];
+	const int n = min(*counter, cap);
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+		AssocCand* c = &cand[t];
 		const AssocProblem P = probs[c->p];
 		const double* a = src + (long long)(P.srcOff + c->i) * 64;
 		const double* b = dst + (long long)(P.dstOff + c->j) * 64;
@@ -327,29 +391,25 @@ __global__ __launch_bounds__(256) void k_assoc_exact(const double* __restrict__ 
 		}
 		c->score = total;
 		const unsigned long long bits = (unsigned long long)__double_as_longlong(total);
-		if (isRow) atomicMin(&rowBest[P.rowBase + c->i], bits);
-		else atomicMin(&colBest[P.colBase + c->j], bits);
+		atomicMin(&rowBest[P.rowBase + c->i], bits);
+		atomicMin(&colBest[P.colBase + c->j], bits);
 	}
 }
 
 // among the pairs that attain the exact minimum: largest destination index per row; count + any source index per column
-__global__ __launch_bounds__(256) void k_assoc_argsel(const AssocProblem* __restrict__ probs, const AssocCand* __restrict__ rowCand,
-														const AssocCand* __restrict__ colCand, const int* __restrict__ counters, int cap,
-														const unsigned long long* __restrict__ rowBest, const unsigned long long* __restrict__ colBest,
-														int* __restrict__ rowArg, int* __restrict__ colArg, int* __restrict__ colCnt) {
-	const int nRow = min(counters[0], cap), nCol = min(counters[1], cap);
-	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nRow + nCol; t += gridDim.x * blockDim.x) {
-		const bool isRow = t < nRow;
-		const AssocCand c = isRow ? rowCand[t] : colCand[t - nRow];
+__global__ __launch_bounds__(256) void k_assoc_argsel(const AssocProblem* __restrict__ probs, const AssocCand* __restrict__ cand,
+														const int* __restrict__ counter, int cap, const unsigned long long* __restrict__ rowBest,
+														const unsigned long long* __restrict__ colBest, int* __restrict__ rowArg, int* __restrict__ colArg,
+														int* __restrict__ colCnt) {
+	const int n = min(*counter, cap);
+	for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+		const AssocCand c = cand[t];
 		const AssocProblem P = probs[c.p];
 		const unsigned long long bits = (unsigned long long)__double_as_longlong(c.score);
-		if (isRow) {
-			if (bits == rowBest[P.rowBase + c.i]) atomicMax(&rowArg[P.rowBase + c.i], c.j);
-		} else {
-			if (bits == colBest[P.colBase + c.j]) {
-				atomicAdd(&colCnt[P.colBase + c.j], 1);
-				atomicMax(&colArg[P.colBase + c.j], c.i);
-			}
+		if (bits == rowBest[P.rowBase + c.i]) atomicMax(&rowArg[P.rowBase + c.i], c.j);
+		if (bits == colBest[P.colBase + c.j]) {
+			atomicAdd(&colCnt[P.colBase + c.j], 1);
+			atomicMax(&colArg[P.colBase + c.j], c.i);
 		}
 	}
 }
@@ -398,26 +458,37 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 		flopsPerPass += 2.0 * ns[p] * (double)nd[p] * 64;
 		if (rowTotal > 0x3fffffffLL || colTotal > 0x3fffffffLL) return BHIP_OK;
 	}
-	// block table: 128 rows per block; split the columns when there are too few row blocks to fill the chip
+	// block table: BLOCK_ROWS rows per block; split the columns when there are too few row blocks to fill the chip
 	long long rowBlocks = 0;
-	for (int p = 0; p < count; p++) rowBlocks += (ns[p] + 127) / 128;
+	for (int p = 0; p < count; p++) rowBlocks += (ns[p] + BLOCK_ROWS - 1) / BLOCK_ROWS;
 	int colSplit = (int)std::max<long long>(1, (1024 + rowBlocks - 1) / rowBlocks);
 	{ const char* e = getenv("BHIP_ASSOC_COLSPLIT"); if (e && atoi(e) > 0) colSplit = atoi(e); }   // tests: force long column sweeps per block
 	for (int p = 0; p < count; p++) {
 		int split = std::min(colSplit, (nd[p] + 63) / 64);
 		int per = (nd[p] + split - 1) / split;
-		per = ((per + 63) / 64) * 64;
-		for (int r0 = 0; r0 < ns[p]; r0 += 128)
+		per = std::min(COL_CAP, ((per + 63) / 64) * 64);
+		for (int r0 = 0; r0 < ns[p]; r0 += BLOCK_ROWS)
 			for (int c0 = 0; c0 < nd[p]; c0 += per) blocks.push_back({p, r0, c0, std::min(nd[p], c0 + per)});
+	}
+	if (count >= 16) {
+		// Workgroup ids go round-robin over the 8 XCDs: give all blocks of a problem the same id residue so that its destination rows are
+		// fetched into ONE XCD's L2 instead of eight (problems are dealt to the residues in turn; short queues are padded with empty entries).
+		std::vector<AssocBlock> q[8];
+		for (const AssocBlock& b : blocks) q[b.p & 7].push_back(b);
+		size_t longest = 0;
+		for (int x = 0; x < 8; x++) longest = std::max(longest, q[x].size());
+		blocks.assign(longest * 8, AssocBlock{0, 0, 0, 0});
+		for (int x = 0; x < 8; x++)
+			for (size_t k = 0; k < q[x].size(); k++) blocks[k * 8 + x] = q[x][k];
 	}
 	const bool shared = dev_src == dev_dst;
 	const long long rowsS = shared ? std::max(maxSrcRow, maxDstRow) : maxSrcRow;
-	const int cap = (int)std::min<long long>(0x3fffffffLL, 4 * (rowTotal + colTotal) + 4096);
+	const int cap = (int)std::min<long long>(0x3fffffffLL, 8 * (rowTotal + colTotal) + 4096);
 
-	BHIP_TRY(W.Fs.reserve(ctx, (size_t)rowsS * 64 * 4));
+	BHIP_TRY(W.Fs.reserve(ctx, (size_t)rowsS * ROW_CHUNKS * 16));
 	BHIP_TRY(W.nrmS.reserve(ctx, (size_t)rowsS * 4));
 	if (!shared) {
-		BHIP_TRY(W.Fd.reserve(ctx, (size_t)maxDstRow * 64 * 4));
+		BHIP_TRY(W.Fd.reserve(ctx, (size_t)maxDstRow * ROW_CHUNKS * 16));
 		BHIP_TRY(W.nrmD.reserve(ctx, (size_t)maxDstRow * 4));
 	}
 	BHIP_TRY(W.probs.reserve(ctx, probs.size() * sizeof(AssocProblem)));
@@ -426,23 +497,26 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	BHIP_TRY(W.thr.reserve(ctx, (size_t)(rowTotal + colTotal) * 4));
 	BHIP_TRY(W.best.reserve(ctx, (size_t)(rowTotal + colTotal) * 8));
 	BHIP_TRY(W.args.reserve(ctx, (size_t)(rowTotal + 2 * colTotal) * 4));
-	BHIP_TRY(W.cand.reserve(ctx, (size_t)cap * 2 * sizeof(AssocCand)));
+	BHIP_TRY(W.cand.reserve(ctx, (size_t)cap * sizeof(AssocCand)));
 	BHIP_TRY(W.flags.reserve(ctx, 64));
 
 	hipStream_t st = ctx->stream;
 	BHIP_HIP(ctx, hipMemcpyAsync(W.probs.p, probs.data(), probs.size() * sizeof(AssocProblem), hipMemcpyHostToDevice, st));
 	BHIP_HIP(ctx, hipMemcpyAsync(W.blocks.p, blocks.data(), blocks.size() * sizeof(AssocBlock), hipMemcpyHostToDevice, st));
 	BHIP_HIP(ctx, hipMemsetAsync(W.flags.p, 0, 64, st));
-	int* flags = W.flags.as<int>();       // [0] non-finite, [1] max norm bits, [2],[3] candidate counters
+	int* flags = W.flags.as<int>();       // [0] non-finite, [1] max norm bits, [2] number of listed pairs
 	int* counters = flags + 2;
-	float* Fs = W.Fs.as<float>();
+	_Float16* Hs = W.Fs.as<_Float16>();
 	float* nS = W.nrmS.as<float>();
-	float* Fd = shared ? Fs : W.Fd.as<float>();
+	_Float16* Hd = shared ? Hs : W.Fd.as<_Float16>();
 	float* nD = shared ? nS : W.nrmD.as<float>();
 	{
-		ProfScope ps(ctx, "k_assoc_prep", (double)rowsS * 64 * 12);
-		hipLaunchKernelGGL(k_assoc_prep, dim3((unsigned)((rowsS + 3) / 4)), dim3(256), 0, st, dev_src, rowsS, Fs, nS, flags);
-		if (!shared) hipLaunchKernelGGL(k_assoc_prep, dim3((unsigned)((maxDstRow + 3) / 4)), dim3(256), 0, st, dev_dst, maxDstRow, Fd, nD, flags);
+		ProfScope ps(ctx, "k_assoc_prep", (double)(rowsS + (shared ? 0 : maxDstRow)) * (2 * 64 * 8 + ROW_CHUNKS * 16));
+		const unsigned gS = (unsigned)((rowsS + 15) / 16), gD = (unsigned)((maxDstRow + 15) / 16);
+		hipLaunchKernelGGL(k_assoc_norms, dim3(gS), dim3(256), 0, st, dev_src, rowsS, nS, flags);
+		if (!shared) hipLaunchKernelGGL(k_assoc_norms, dim3(gD), dim3(256), 0, st, dev_dst, maxDstRow, nD, flags);
+		hipLaunchKernelGGL(k_assoc_half, dim3(gS), dim3(256), 0, st, dev_src, rowsS, nS, flags, Hs);
+		if (!shared) hipLaunchKernelGGL(k_assoc_half, dim3(gD), dim3(256), 0, st, dev_dst, maxDstRow, nD, flags, Hd);
 	}
 	unsigned int* rowKey = W.keys.as<unsigned int>();
 	unsigned int* colKey = rowKey + rowTotal;
@@ -460,9 +534,9 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	BHIP_HIP(ctx, hipMemsetAsync(colCnt, 0, (size_t)colTotal * 4, st));
 
 	MfmaArgs A;
-	A.Fs = Fs; A.Fd = Fd; A.nrmS = nS; A.nrmD = nD; A.probs = W.probs.as<AssocProblem>(); A.blocks = W.blocks.as<AssocBlock>();
+	A.Hs = (const uint4*)Hs; A.Hd = (const uint4*)Hd; A.probs = W.probs.as<AssocProblem>(); A.blocks = W.blocks.as<AssocBlock>();
 	A.rowKey = rowKey; A.colKey = colKey; A.rowThr = rowThr; A.colThr = colThr;
-	A.rowCand = W.cand.as<AssocCand>(); A.colCand = A.rowCand + cap; A.counters = counters; A.cap = cap;
+	A.cand = W.cand.as<AssocCand>(); A.counter = counters; A.cap = cap;
 	const unsigned nblocks = (unsigned)blocks.size();
 	{
 		ProfScope ps(ctx, "k_assoc_mfma_pass1", 0, flopsPerPass);
@@ -477,14 +551,14 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	}
 	{
 		ProfScope ps(ctx, "k_assoc_exact");
-		hipLaunchKernelGGL(k_assoc_exact, dim3(1024), dim3(256), 0, st, dev_src, dev_dst, A.probs, A.rowCand, A.colCand, counters, cap, rowBest, colBest);
-		hipLaunchKernelGGL(k_assoc_argsel, dim3(1024), dim3(256), 0, st, A.probs, A.rowCand, A.colCand, counters, cap, rowBest, colBest, rowArg, colArg, colCnt);
+		hipLaunchKernelGGL(k_assoc_exact, dim3(1024), dim3(256), 0, st, dev_src, dev_dst, A.probs, A.cand, counters, cap, rowBest, colBest);
+		hipLaunchKernelGGL(k_assoc_argsel, dim3(1024), dim3(256), 0, st, A.probs, A.cand, counters, cap, rowBest, colBest, rowArg, colArg, colCnt);
 	}
 	// degenerate inputs? (one small read-back; the result kernels below are only trusted when the flags are clean)
 	BHIP_HIP(ctx, hipMemcpyAsync(ctx->hostScratch, flags, 16, hipMemcpyDeviceToHost, st));
 	BHIP_HIP(ctx, hipStreamSynchronize(st));
 	const int* hf = ctx->hostScratch;
-	if (hf[0] != 0 || hf[2] > cap || hf[3] > cap) return BHIP_OK;  // *usedMfma stays 0
+	if (hf[0] != 0 || hf[2] > cap) return BHIP_OK;  // *usedMfma stays 0
 	int maxNs = 0;
 	for (int p = 0; p < count; p++) maxNs = std::max(maxNs, ns[p]);
 	hipLaunchKernelGGL(k_assoc_resolve, dim3((maxNs + 255) / 256, count), dim3(256), 0, st, A.probs, maxErr, backwards, rowBest, rowArg, colArg, colCnt,
