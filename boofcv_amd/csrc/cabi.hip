@@ -134,6 +134,7 @@ struct FhOctavePlan {
 	// execution plan (FhDetector::planExecution)
 	bool fused = false, fixed = false;
 	int shareFrom[BHIP_MAX_LEVELS];   // level of the previous octave with the same kernel size, or -1
+	bool onDemand[BHIP_MAX_LEVELS];   // stand-alone octave: outer level left to k_nms_scalespace (evaluated around the NMS maxima only)
 	int exportSlot[BHIP_MAX_LEVELS];  // fused producer: slot of this level in the export buffer, or -1
 	int nexport = 0;
 	size_t intenOff = 0, expOff = 0;  // floats, per-image strides below
@@ -194,6 +195,7 @@ struct FhDetector {
 	}
 
 	static bool noShare() { return bhip_env_flag("BHIP_DETECT_NOSHARE"); }   // parity cross-check of the shared-level plan
+	static bool denseOuter() { return bhip_env_flag("BHIP_DETECT_DENSE"); }  // parity cross-check: compute the outer levels of every octave densely
 	// Which octaves run fused, and which levels are copied from the octave below instead of being recomputed.  A box-filter response
 	// depends on (pixel, kernel size) only, and the default schedule repeats sizes: 15,27 | 27,51 | 51,99 are levels 1,3 of one octave and
 	// levels 0,1 of the next, on a lattice twice as coarse.  Sharing is enabled where the unrolled inner form and the clamped border
@@ -208,19 +210,29 @@ struct FhDetector {
 			o.fixed = o.fused && bhip_fused_is_fixed(o.skip, o.nlevels, o.sizes, cfg.extractRadius);
 			if (intTaps && !o.fixed) o.fused = false;   // integer taps: compile-time-geometry fused kernel or the stand-alone kernels
 			o.nexport = 0;
-			for (int i = 0; i < BHIP_MAX_LEVELS; i++) { o.shareFrom[i] = -1; o.exportSlot[i] = -1; }
+			for (int i = 0; i < BHIP_MAX_LEVELS; i++) { o.shareFrom[i] = -1; o.exportSlot[i] = -1; o.onDemand[i] = false; }
 		}
-		if (noShare()) return;
-		for (size_t k = 1; k < plan.size(); k++) {
+		// The first and last level of an octave are only read around the NMS maxima of their neighbour level: a stand-alone octave leaves
+		// them to k_nms_scalespace unless they can be copied from the octave below.  (N-best selection reads whole levels: dense.)
+		const bool sparseOuter = !denseOuter() && !nBest();
+		for (size_t k = 0; k < plan.size(); k++) {
 			FhOctavePlan& c = plan[k];
-			FhOctavePlan& p = plan[k - 1];
-			if (c.fused || c.skip != 2 * p.skip) continue;
-			if (p.fused && !p.fixed) continue;
+			if (k > 0 && !noShare()) shareLevels(c, plan[k - 1]);
+			if (!c.fused && sparseOuter && c.nlevels >= 3)
+				for (int i : {0, c.nlevels - 1})
+					if (c.shareFrom[i] < 0) c.onDemand[i] = true;
+		}
+	}
+	void shareLevels(FhOctavePlan& c, FhOctavePlan& p) {
+		{
+			if (c.fused || c.skip != 2 * p.skip) return;
+			if (p.fused && !p.fixed) return;
 			for (int i = 0; i < c.nlevels; i++) {
 				const int size = c.sizes[i];
 				if (size % 3 != 0 || size % 2 != 1) continue;
 				for (int j = 0; j < p.nlevels; j++) {
 					if (p.sizes[j] != size) continue;
+					if (!p.fused && p.onDemand[j]) break;   // the producer does not hold this level
 					if (p.fused) {
 						if (p.exportSlot[j] < 0) {
 							if (p.nexport >= 2) break;
@@ -308,11 +320,16 @@ struct FhDetector {
 					if (p.fused) from[i] = HessLevelSource{expBuf.as<float>() + p.expOff + (size_t)p.exportSlot[j] * levelStride, p.expImageStride, o.w, 1};
 					else from[i] = HessLevelSource{inten.as<float>() + p.intenOff + (size_t)j * p.w * p.h, p.intenImageStride, p.w, 2};
 				}
-				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, base, levelStride, imageStride, o.w, from, intTaps));
+				unsigned int skipMask = 0;
+				for (int i = 0; i < o.nlevels; i++)
+					if (o.onDemand[i]) skipMask |= 1u << i;
+				BHIP_TRY(bhip_launch_hessian(ctx, ii, batch, o.skip, o.nlevels, o.sizes, base, levelStride, imageStride, o.w, from, intTaps, skipMask));
 				for (auto& m : o.mids) {
-					BHIP_TRY(bhip_launch_nms_scalespace(ctx, base + (m.level - 1) * levelStride, base + m.level * levelStride, base + (m.level + 1) * levelStride,
-														imageStride, o.w, batch, m.p, cfg.extractRadius, cfg.detectThreshold, bitmap.as<unsigned int>(),
-														bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap, nBest()));
+					const float* lower = o.onDemand[m.level - 1] ? nullptr : base + (m.level - 1) * levelStride;
+					const float* upper = o.onDemand[m.level + 1] ? nullptr : base + (m.level + 1) * levelStride;
+					BHIP_TRY(bhip_launch_nms_scalespace(ctx, lower, base + m.level * levelStride, upper, imageStride, o.w, batch, m.p, cfg.extractRadius,
+														cfg.detectThreshold, bitmap.as<unsigned int>(), bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap,
+														nBest(), &ii, intTaps));
 				}
 			}
 			BHIP_TRY(bhip_launch_word_prefix(ctx, bitmap.as<unsigned int>(), bitmapWords, batch, prefix.as<unsigned int>(), count.as<int>() + batch));

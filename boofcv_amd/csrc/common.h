@@ -166,7 +166,8 @@ struct HessLevelSource {
 	int step;                // 1: src already has this octave's layout, 2: take every second pixel
 };
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
-						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr, bool intTaps = false);
+						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr, bool intTaps = false,
+						unsigned int skipMask = 0);   // skipMask: levels this launch does not produce
 
 // describe-kernel options beyond the grey float default (see DescParams): colour SURF bands (nBands > 0), the orientation's object
 // radius factor, integer taps (GrayS32 integral images)
@@ -186,7 +187,7 @@ struct DetectLevelParams {
 };
 int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
 							   DetectLevelParams p, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							   int cap, bool listOnly = false);
+							   int cap, bool listOnly = false, const ImgView* ii = nullptr, bool intTaps = false);   // lower / upper == nullptr: evaluated on demand from *ii
 int bhip_launch_select_nbest(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
 							 DetectLevelParams p, int radius, int target, const unsigned int* bitmap, const unsigned int* prefix, int bitmapWords,
 							 const KeyPoint* nms, int cap, float* keyBuf, int* idxBuf, KeyPoint* out, int* levelStart, int* levelCount, int levelIndex, int nlv);

@@ -12,7 +12,7 @@
 // (USE_CONCURRENT=false) is block-raster order.  Each pixel is tested by one thread; an accepted pixel sets bit (blockY*nbx+blockX) of a
 // per-image bitmap, which makes the ordering a popcount-prefix: rank = #bits below.  No sort, no atomics on the ordering path.
 // fp32 compares only, so keypoint indices are bit-exact whenever the intensity image is.
-#include "common.h"
+#include "hessian_dev.h"
 #include <cfloat>
 
 // strict-maximum test of NonMaxBlockSearchStrict.Max for pixel (x,y) with value v.  The window is read without early exits so the
@@ -52,29 +52,18 @@ __device__ __forceinline__ float polyPeak(float lower, float middle, float upper
 	return -b / (2.0f * a);
 }
 
-// FastHessianFeatureDetector.findLocalScaleSpaceMax :268-294 for one NMS maximum (x,y) of the middle level with value val: border guard,
-// checkMax on the lower and upper level, polyPeak fits.  Fills kp.x / kp.y / kp.scale and returns true when the point is a key point.
-__device__ __forceinline__ bool scaleSpaceKeyPoint(const float* __restrict__ lower, const float* __restrict__ mid, const float* __restrict__ upper, int stride,
-													const DetectLevelParams& p, int r, int x, int y, float val, KeyPoint& kp) {
-	const int w = p.w, h = p.h;
-	// candidates hugging the ignore border are dropped
-	const int ignoreR = p.border + r;
-	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) return false;
-	// checkMax on the lower and upper level: all 9 neighbours strictly below val (0 outside the image; never hit since ignoreR >= 1)
+// FastHessianFeatureDetector.findLocalScaleSpaceMax :268-294 for one NMS maximum (x,y) of the middle level with value val, given the 3x3
+// neighbourhoods lo[] / up[] of the lower and upper level (row-major, centre at [4]): checkMax on both, polyPeak fits.
+__device__ __forceinline__ bool scaleSpaceFit(const float* lo, const float* up, const float* __restrict__ mid, int stride, const DetectLevelParams& p, int x,
+											   int y, float val, KeyPoint& kp) {
 	bool below = true;
 #pragma unroll
-	for (int j = y - 1; j <= y + 1; j++)
-#pragma unroll
-		for (int i = x - 1; i <= x + 1; i++) {
-			const bool in = i >= 0 && i < w && j >= 0 && j < h;
-			const float lo = in ? lower[(long long)j * stride + i] : 0.0f;
-			const float up = in ? upper[(long long)j * stride + i] : 0.0f;
-			if (lo >= val || up >= val) below = false;
-		}
+	for (int k = 0; k < 9; k++)
+		if (lo[k] >= val || up[k] >= val) below = false;
 	if (!below) return false;
 	const float peakX = polyPeak(mid[(long long)y * stride + x - 1], val, mid[(long long)y * stride + x + 1]);
 	const float peakY = polyPeak(mid[(long long)(y - 1) * stride + x], val, mid[(long long)(y + 1) * stride + x]);
-	const float peakS = polyPeak(lower[(long long)y * stride + x], val, upper[(long long)y * stride + x]);
+	const float peakS = polyPeak(lo[4], val, up[4]);
 	const float interpX = ((float)x + peakX) * (float)p.skip;
 	const float interpY = ((float)y + peakY) * (float)p.skip;
 	const float interpS = (float)p.sizeMid + peakS * (float)(p.sizeMid - p.sizeLower);
@@ -82,6 +71,40 @@ __device__ __forceinline__ bool scaleSpaceKeyPoint(const float* __restrict__ low
 	kp.y = (double)interpY;
 	kp.scale = 1.2 * (double)interpS / 9.0;
 	return true;
+}
+
+// An outer level of an octave (first / last kernel size) is only ever read around the NMS maxima of its neighbour level, so the
+// stand-alone path may leave it uncomputed: its 3x3 values are then evaluated here, from the integral image, exactly as k_hessian would.
+struct VirtualLevel {
+	HessLevel L;       // geometry on this octave's lattice
+	int on;            // 0: the level is in memory
+};
+struct NmsVirtual {
+	ImgView ii;
+	int intTaps;
+	VirtualLevel lower, upper;
+};
+__device__ __forceinline__ void neighbourhood9(const float* __restrict__ lvl, int stride, int w, int h, int x, int y, float* out) {
+	// 0 outside the image (never hit: candidates hugging the ignore border were dropped)
+#pragma unroll
+	for (int j = -1; j <= 1; j++)
+#pragma unroll
+		for (int i = -1; i <= 1; i++) {
+			const int xx = x + i, yy = y + j;
+			out[(j + 1) * 3 + i + 1] = (xx >= 0 && xx < w && yy >= 0 && yy < h) ? lvl[(long long)yy * stride + xx] : 0.0f;
+		}
+}
+// border guard + scaleSpaceFit on levels held in memory.  Fills kp.x / kp.y / kp.scale and returns true when the point is a key point.
+__device__ __forceinline__ bool scaleSpaceKeyPoint(const float* __restrict__ lower, const float* __restrict__ mid, const float* __restrict__ upper, int stride,
+													const DetectLevelParams& p, int r, int x, int y, float val, KeyPoint& kp) {
+	const int w = p.w, h = p.h;
+	// candidates hugging the ignore border are dropped
+	const int ignoreR = p.border + r;
+	if (x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR) return false;
+	float lo[9], up[9];
+	neighbourhood9(lower, stride, w, h, x, y, lo);
+	neighbourhood9(upper, stride, w, h, x, y, up);
+	return scaleSpaceFit(lo, up, mid, stride, p, x, y, val, kp);
 }
 
 struct NmsParams {
@@ -99,9 +122,23 @@ struct NmsParams {
 	int* candCount;
 	int cap;
 	int listOnly;
+	NmsVirtual virt;
 };
 
+#define VSURV 256     // maxima per pass of k_nms_scalespace that wait for an evaluated outer level (one pass tests 256 candidates)
 #define NMS_ROWS 4   // rows per thread: the column neighbours are shared and the grid has 4x fewer, longer-lived blocks
+__device__ __forceinline__ void emitKeyPoint(const NmsParams& P, int img, int x, int y, KeyPoint kp) {
+	const int b = P.p.border, step = P.radius + 1;
+	const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
+	atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
+	const int slot = atomicAdd(&P.candCount[img], 1);
+	if (slot < P.cap) {
+		kp.key = bit;
+		kp.pad = 0;
+		P.cand[(long long)img * P.cap + slot] = kp;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 	const int b = P.p.border;
 	const int w = P.p.w, h = P.p.h;
@@ -145,36 +182,102 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 	}
 	__syncthreads();
 	const int ncand = candCount;
-	for (int ci = threadIdx.x; ci < ncand; ci += blockDim.x) {
-		const int code = candList[ci];
-		const int x = b + blockIdx.x * blockDim.x + (code & 0xFFFF);
-		const int y = yBase + (code >> 16);
-		const float val = mid[(long long)y * stride + x];
-		if (!(r == 2 ? strictLocalMax<2>(mid, stride, w, h, x, y, r, val, P.threshold) : strictLocalMax<0>(mid, stride, w, h, x, y, r, val, P.threshold))) continue;
-
-		const int step = r + 1;
-		const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
-		KeyPoint kp;
-		if (P.listOnly) {
-			// maxFeaturesPerScale > 0: every NMS maximum is listed with its intensity; selection and the scale-space test follow in k_select_nbest
-			kp.x = (double)x; kp.y = (double)y; kp.scale = (double)val;
-		} else if (!scaleSpaceKeyPoint(P.lower + (long long)img * P.imageStride, mid, P.upper + (long long)img * P.imageStride, stride, P.p, r, x, y, val, kp)) continue;
-		atomicOr(&P.bitmap[(long long)img * P.bitmapWords + (bit >> 5)], 1u << (bit & 31));
-		const int slot = atomicAdd(&P.candCount[img], 1);
-		if (slot < P.cap) {
-			kp.key = bit;
-			kp.pad = 0;
-			P.cand[(long long)img * P.cap + slot] = kp;
+	const bool anyVirtual = P.virt.lower.on || P.virt.upper.on;   // launch-uniform
+	// maxima that still need an outer level evaluated: (x, y) and, per evaluated level, the nine responses (one thread per response)
+	__shared__ int survXY[VSURV];
+	__shared__ float survVal[VSURV][18];
+	__shared__ int survCount;
+	for (int c0 = 0; c0 < ncand; c0 += blockDim.x) {   // workgroup-uniform trip count
+		if (anyVirtual) {
+			if (threadIdx.x == 0) survCount = 0;
+			__syncthreads();
+		}
+		const int ci = c0 + threadIdx.x;
+		if (ci < ncand) {
+			const int code = candList[ci];
+			const int x = b + blockIdx.x * blockDim.x + (code & 0xFFFF);
+			const int y = yBase + (code >> 16);
+			const float val = mid[(long long)y * stride + x];
+			if (r == 2 ? strictLocalMax<2>(mid, stride, w, h, x, y, r, val, P.threshold) : strictLocalMax<0>(mid, stride, w, h, x, y, r, val, P.threshold)) {
+				if (P.listOnly) {
+					// maxFeaturesPerScale > 0: every NMS maximum is listed with its intensity; selection and the scale-space test follow in k_select_nbest
+					KeyPoint kp;
+					kp.x = (double)x; kp.y = (double)y; kp.scale = (double)val;
+					emitKeyPoint(P, img, x, y, kp);
+				} else if (!anyVirtual) {
+					KeyPoint kp;
+					if (scaleSpaceKeyPoint(P.lower + (long long)img * P.imageStride, mid, P.upper + (long long)img * P.imageStride, stride, P.p, r, x, y, val, kp))
+						emitKeyPoint(P, img, x, y, kp);
+				} else {
+					const int ignoreR = b + r;
+					if (!(x < ignoreR || x >= w - ignoreR || y < ignoreR || y >= h - ignoreR)) {
+						// the level held in memory first: most maxima lose against it and never reach the evaluated level
+						float nb[9];
+						bool alive = true;
+						if (!P.virt.lower.on || !P.virt.upper.on) {
+							neighbourhood9(!P.virt.lower.on ? P.lower + (long long)img * P.imageStride : P.upper + (long long)img * P.imageStride, stride, w, h, x, y, nb);
+#pragma unroll
+							for (int k = 0; k < 9; k++)
+								if (nb[k] >= val) alive = false;
+						}
+						if (alive) {
+							const int s = atomicAdd(&survCount, 1);   // <= 256 per pass = VSURV
+							survXY[s] = (y << 16) | x;
+							if (!P.virt.lower.on || !P.virt.upper.on) {
+								const int o = !P.virt.lower.on ? 0 : 9;
+#pragma unroll
+								for (int k = 0; k < 9; k++) survVal[s][o + k] = nb[k];
+							}
+						}
+					}
+				}
+			}
+		}
+		if (anyVirtual) {
+			__syncthreads();
+			const int ns = survCount;
+			const int per = (P.virt.lower.on ? 9 : 0) + (P.virt.upper.on ? 9 : 0);
+			for (int t = threadIdx.x; t < ns * per; t += blockDim.x) {
+				const int s = t / per;
+				int k = t - s * per;
+				const bool up = !P.virt.lower.on || k >= 9;
+				if (k >= 9) k -= 9;
+				const int xy = survXY[s];
+				const int xx = (xy & 0xFFFF) + k % 3 - 1, yy = (xy >> 16) + k / 3 - 1;
+				const HessLevel& L = up ? P.virt.upper.L : P.virt.lower.L;
+				const float* base = P.virt.ii.data + (long long)img * P.virt.ii.imageStride;
+				float v = 0.0f;   // 0 outside the image (never hit: maxima hugging the ignore border were dropped)
+				if (xx >= 0 && xx < w && yy >= 0 && yy < h)
+					v = P.virt.intTaps ? hessianCompute<int>((const int*)base, P.virt.ii.stride, P.virt.ii.width, P.virt.ii.height, L, P.p.skip, w, h, xx, yy)
+									   : hessianCompute<float>(base, P.virt.ii.stride, P.virt.ii.width, P.virt.ii.height, L, P.p.skip, w, h, xx, yy);
+				survVal[s][(up ? 9 : 0) + k] = v;
+			}
+			__syncthreads();
+			for (int s = threadIdx.x; s < ns; s += blockDim.x) {
+				const int xy = survXY[s];
+				const int x = xy & 0xFFFF, y = xy >> 16;
+				KeyPoint kp;
+				if (scaleSpaceFit(&survVal[s][0], &survVal[s][9], mid, stride, P.p, x, y, mid[(long long)y * stride + x], kp)) emitKeyPoint(P, img, x, y, kp);
+			}
 		}
 	}
 }
 
 int bhip_launch_nms_scalespace(bhip_ctx* ctx, const float* lower, const float* mid, const float* upper, long long imageStride, int stride, int batch,
 							   DetectLevelParams p, int radius, float threshold, unsigned int* bitmap, int bitmapWords, KeyPoint* cand, int* candCount,
-							   int cap, bool listOnly) {
+							   int cap, bool listOnly, const ImgView* ii, bool intTaps) {
 	const int rw = p.w - 2 * p.border, rh = p.h - 2 * p.border;
 	if (rw <= 0 || rh <= 0) return BHIP_OK;
-	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap, listOnly ? 1 : 0};
+	NmsParams P{lower, mid, upper, imageStride, stride, p, radius, threshold, bitmap, bitmapWords, cand, candCount, cap, listOnly ? 1 : 0, {}};
+	P.virt.lower.on = P.virt.upper.on = 0;
+	P.virt.intTaps = intTaps ? 1 : 0;
+	if (!lower || !upper) {
+		// an outer level that was not computed: evaluated on demand from the integral image
+		if (!ii || listOnly) return bhip_fail(ctx, BHIP_ERR_INVALID, "a level that is not in memory needs the integral image");
+		P.virt.ii = *ii;
+		if (!lower) { P.virt.lower.on = 1; P.virt.lower.L = bhipMakeHessLevel(p.sizeLower, p.skip); }
+		if (!upper) { P.virt.upper.on = 1; P.virt.upper.L = bhipMakeHessLevel(p.sizeUpper, p.skip); }
+	}
 	dim3 grid((rw + 255) / 256, (rh + NMS_ROWS - 1) / NMS_ROWS, batch);
 	{
 		ProfScope ps(ctx, "k_nms_scalespace", 4.0 * p.w * p.h * batch);  // the mid level read once

@@ -778,9 +778,10 @@ def test_orientation_degenerate_regimes(api, orc):
 
 @pytest.mark.parametrize("w,h,seed,hi", [(700, 520, 21, 255), (400, 300, 6, 100), (403, 301, 8, 100)])
 def test_detector_plans_agree(api, orc, tmp_path, w, h, seed, hi):
-    """The detector has three execution plans that must give the same key points bit for bit: fused octaves + levels shared between
-    octaves (default), no sharing (BHIP_DETECT_NOSHARE=1), and the stand-alone kernels for every octave (BHIP_DETECT_UNFUSED=1, with
-    and without sharing).  The switches are read once per process, so the variants run in child processes."""
+    """The detector's execution plans must give the same key points bit for bit: fused octaves + levels shared between octaves + outer
+    levels of the stand-alone octaves evaluated on demand (default), no sharing (BHIP_DETECT_NOSHARE=1), the stand-alone kernels for every
+    octave (BHIP_DETECT_UNFUSED=1, with and without sharing), and every level computed densely (BHIP_DETECT_DENSE=1).  The switches are
+    read by the child processes the variants run in."""
     import os, subprocess, sys
     # (400, 300, 6): a key point next to the column where octave 1 evaluates size 27 with the border form and octave 0 with the inner form
     img = orc.noise_image(w, h, seed, 0, hi)
@@ -795,7 +796,8 @@ def test_detector_plans_agree(api, orc, tmp_path, w, h, seed, hi):
             "fh.detect(api.IntegralImageOps.transform(api.GrayF32.wrap(a))); "
             "np.save(%r, fh.getFoundPoints())")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for k, env in enumerate([{"BHIP_DETECT_NOSHARE": "1"}, {"BHIP_DETECT_UNFUSED": "1"}, {"BHIP_DETECT_UNFUSED": "1", "BHIP_DETECT_NOSHARE": "1"}]):
+    for k, env in enumerate([{"BHIP_DETECT_NOSHARE": "1"}, {"BHIP_DETECT_UNFUSED": "1"}, {"BHIP_DETECT_UNFUSED": "1", "BHIP_DETECT_NOSHARE": "1"},
+                             {"BHIP_DETECT_DENSE": "1"}, {"BHIP_DETECT_UNFUSED": "1", "BHIP_DETECT_DENSE": "1"}]):
         out = str(tmp_path / ("kp%d.npy" % k))
         e = dict(os.environ); e.update(env)
         subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "img.npy"), out)], check=True, env=e, timeout=300)
