@@ -438,9 +438,8 @@ __device__ __forceinline__ void fusedLevelDense(const FusedParams& P, const T* i
 // level 3 above mid level 2) arrives as "all nine neighbours below val" + its centre value; the other neighbour level is the other dense
 // mid level.
 template <class G, int SKIP, int R>
-__device__ __forceinline__ void fusedFinish(const FusedParams& P, const float* mid1, const float* mid2, bool outerBelow, float outerCentre, int m, int px, int py,
-											int x, int y, float val, int img) {
-	const FusedMid M = P.mid[m];
+__device__ __forceinline__ void fusedFinish(const FusedParams& P, const FusedMid& M, const float* mid1, const float* mid2, bool outerBelow, float outerCentre,
+											int px, int py, int x, int y, float val, int img) {
 	const bool lowMid = M.level == 1;
 	const float* self = (lowMid ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
 	const float* other = (lowMid ? mid2 : mid1) + (py + R) * G::ITp + (px + R);
@@ -505,11 +504,55 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const int X0 = (x0 - R) * SKIP - G::rFmax - 1, Y0 = (y0 - R) * SKIP - G::rFmax - 1;
 	bool staged = false;
+	// Interior tiles (all but those along the image frame): the patch lies inside the image and, with the tile pitch a multiple of four
+	// columns, starts on (SKIP == 1) or two columns after (SKIP == 2) a 16-byte boundary -- whole rows are fetched with 16-byte loads,
+	// no per-element guards.  One (row, 4-column group) item per thread and pass; all loads are issued before the first LDS store.
+	if constexpr (SKIP == 1 || SKIP == 2) {
+		constexpr int SH = SKIP == 1 ? 0 : 2;                  // patch column 0 sits SH elements after the aligned start
+		constexpr int IW4 = (G::IW + SH + 3) / 4;
+		constexpr int ITEMS = G::IH * IW4, NIT = (ITEMS + 255) / 256;
+		const T* src0 = d + (long long)Y0 * stride + (X0 - SH);
+		const bool vecOk = !BHIP_ABLATE(P, 4) && X0 - SH >= 0 && Y0 >= 0 && X0 - SH + 4 * IW4 <= W && Y0 + G::IH <= H && (stride & 3) == 0 &&
+						   (((unsigned long long)src0) & 15ull) == 0;
+		if (vecOk) {
+			int4 v[NIT];
+#pragma unroll
+			for (int it = 0; it < NIT; it++) {
+				const int item = tid + 256 * it;
+				if (item < ITEMS) {
+					const int row = item / IW4, c4 = item - row * IW4;
+					v[it] = *(const int4*)(src0 + (long long)row * stride + 4 * c4);
+				}
+			}
+#pragma unroll
+			for (int it = 0; it < NIT; it++) {
+				const int item = tid + 256 * it;
+				if (item < ITEMS) {
+					const int row = item / IW4, c4 = item - row * IW4;
+					const int e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+					if constexpr (SKIP == 1) {
+						T* dst = iiT + row * G::IWp + 4 * c4;
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							if (4 * c4 + k < G::IW) dst[k] = __builtin_bit_cast(T, e[k]);
+					} else {
+						// patch column rx = 4 c4 + k - 2: k = 0, 2 are even columns (plane 0), k = 1, 3 odd (plane 1), slots 2 c4 - 1 and 2 c4
+						T* p0 = iiT + row * G::IWp + 2 * c4;
+						T* p1 = p0 + G::plane;
+						if (c4 > 0) { p0[-1] = __builtin_bit_cast(T, e[0]); p1[-1] = __builtin_bit_cast(T, e[1]); }
+						if (4 * c4 < G::IW) p0[0] = __builtin_bit_cast(T, e[2]);
+						if (4 * c4 + 1 < G::IW) p1[0] = __builtin_bit_cast(T, e[3]);
+					}
+				}
+			}
+			staged = true;
+		}
+	}
 	if constexpr (SKIP == 2 && (G::IW % 2 == 0)) {
 		// the patch origin is an even column, so with an even row stride every row of the patch is a run of aligned float2 -- half the load
 		// instructions of the scalar path below (this kernel is bound by staging: ~9 k floats per tile); the two halves of a pair go to the two
 		// column-phase planes at the same index
-		if (!BHIP_ABLATE(P, 4) && (stride & 1) == 0 && (W & 1) == 0 && (((unsigned long long)d) & 7ull) == 0) {
+		if (!staged && !BHIP_ABLATE(P, 4) && (stride & 1) == 0 && (W & 1) == 0 && (((unsigned long long)d) & 7ull) == 0) {
 			const int tx = tid & 63, ty = tid >> 6;
 			constexpr int PAIRS = G::IW / 2;
 			static_assert(PAIRS <= 64, "one lane per float2 of a patch row");
@@ -577,6 +620,8 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	// already a strict (2R+1)^2 maximum of a mid level (1 or 2), so only the two mid levels are built densely over the tile; the outer
 	// levels are evaluated on demand at the few NMS survivors (nine values each).  Same functions of (pixel, kernel size), same decisions.
 	static_assert(NL == 4, "two mid levels between two outer levels");
+	// the (at most two) mid-level records as wave-uniform values: indexing P.mid[] with a per-lane m is a kernarg load + wait per use
+	const FusedMid M0 = P.mid[0], M1 = P.mid[P.nmid > 1 ? 1 : 0];
 	float* mid1 = inten;                          // level 1  [ITH][ITp]
 	float* mid2 = inten + G::ITH * G::ITp;        // level 2
 	int* survList = (int*)(inten + 2 * G::ITH * G::ITp);   // [SURV] packed (m << 16 | py << 8 | px)
@@ -620,10 +665,10 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		for (int row = slice; row < P.nmid * G::TY && !BHIP_ABLATE(P, 2); row += SL) {
 			const int m = row / G::TY, py = row - m * G::TY;
 			if (px >= G::TX) continue;
-			const float* mid = (P.mid[m].level == 1 ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
+			const float* mid = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
 			const float val = mid[0];
 			if (!(val >= P.threshold) || val == FLT_MAX) continue;
-			const int b = P.mid[m].border;
+			const int b = m == 0 ? M0.border : M1.border;
 			const int y = y0 + py;
 			if (x < b || x >= P.w - b || y < b || y >= P.h - b) continue;
 			// most pixels above the threshold lose against a direct neighbour: four reads settle them before the full window is fetched
@@ -656,19 +701,20 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			const int code = survList[base + sv];
 			const int m = code >> 16, py = (code >> 8) & 0xff, px = code & 0xff;
 			const int x = x0 + px + q % 3 - 1, y = y0 + py + q / 3 - 1;
-			sparse[it] = P.mid[m].level == 1 ? fusedPixelCall<G, SKIP, 0, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0)
-											 : fusedPixelCall<G, SKIP, 3, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0);
+			sparse[it] = (m == 0 ? M0.level : M1.level) == 1 ? fusedPixelCall<G, SKIP, 0, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0)
+															  : fusedPixelCall<G, SKIP, 3, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0);
 		}
 		__syncthreads();
 		for (int sv = tid; sv < nHere; sv += 256) {
 			const int code = survList[base + sv];
 			const int m = code >> 16, py = (code >> 8) & 0xff, px = code & 0xff;
-			const float val = (P.mid[m].level == 1 ? mid1 : mid2)[(py + R) * G::ITp + (px + R)];
+			const float val = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2)[(py + R) * G::ITp + (px + R)];
 			bool below = true;
 #pragma unroll
 			for (int q = 0; q < 9; q++)
 				if (sparse[sv * 9 + q] >= val) below = false;
-			fusedFinish<G, SKIP, R>(P, mid1, mid2, below, sparse[sv * 9 + 4], m, px, py, x0 + px, y0 + py, val, img);
+			if (m == 0) fusedFinish<G, SKIP, R>(P, M0, mid1, mid2, below, sparse[sv * 9 + 4], px, py, x0 + px, y0 + py, val, img);
+			else fusedFinish<G, SKIP, R>(P, M1, mid1, mid2, below, sparse[sv * 9 + 4], px, py, x0 + px, y0 + py, val, img);
 		}
 		if (base + G::CHUNK < nSurv) __syncthreads();
 	}
