@@ -261,7 +261,10 @@ struct FixedGeo {
 	// LDS: the patch, the two dense mid levels (1 and 2 of the four), survivor list + their nine sparse outer-level values
 	static constexpr int SURV = 2 * ((TX + R) / (R + 1)) * ((TY + R) / (R + 1));   // strict (2R+1)^2 maxima of two mid levels: one per (R+1)^2 block at most
 	static constexpr int CHUNK = 64;   // survivors whose nine outer-level values are held at a time
-	static constexpr int ldsFloats = SKIP * plane + 2 * ITH * ITp + SURV + CHUNK * 9 + 4;
+	static constexpr int NCAND = TX * TY + 2;                     // two mid levels, at most every second core pixel (rounded up) each
+	static_assert(TX < 64 && TY < 64, "16-bit NMS candidate codes");
+	static constexpr int SPARSE = CHUNK * 9 > (NCAND + 1) / 2 ? CHUNK * 9 : (NCAND + 1) / 2;   // floats: sparse values, before that the candidate codes
+	static constexpr int ldsFloats = SKIP * plane + 2 * ITH * ITp + SURV + SPARSE + 4;
 	static constexpr int K0 = rFmax + 1;                          // column of (xx) inside the patch, minus SKIP*(x - x0 + R)
 	// LDS offset of the tap at (row offset ro, column offset co) relative to the pixel's base pointer (row yy-Y0, column slot x-x0+R)
 	static constexpr int tap(int ro, int co) { return ((K0 + co) % SKIP) * plane + ro * IWp + (K0 + co) / SKIP; }
@@ -626,8 +629,10 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	float* mid2 = inten + G::ITH * G::ITp;        // level 2
 	int* survList = (int*)(inten + 2 * G::ITH * G::ITp);   // [SURV] packed (m << 16 | py << 8 | px)
 	float* sparse = (float*)(survList + G::SURV);          // [SURV][9] outer-level values around each survivor
-	int* survCount = (int*)(sparse + G::CHUNK * 9);
-	if (tid == 0) *survCount = 0;
+	int* survCount = (int*)(sparse + G::SPARSE);
+	int* candCount = survCount + 1;
+	unsigned short* candList = (unsigned short*)sparse;    // [NCAND] pixels above the threshold and their four direct neighbours (m << 12 | py << 6 | px); dead before `sparse` is written
+	if (tid == 0) { *survCount = 0; *candCount = 0; }
 	if (!BHIP_ABLATE(P, 1)) {
 		fusedLevelDense<G, SKIP, R, 1, T>(P, iiT, mid1, tid, x0, y0, X0, Y0);
 		fusedLevelDense<G, SKIP, R, 2, T>(P, iiT, mid2, tid, x0, y0, X0, Y0);
@@ -656,26 +661,37 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		}
 	}
 
-	// ---- strict (2R+1)^2 maxima of the two mid levels.  Thread = one core column of one (level, row-phase) slice; rows are walked with the
-	// threshold test first: almost every pixel ends there with one LDS read.
+	// ---- strict (2R+1)^2 maxima of the two mid levels, in two steps so that no wave walks the full window for one or two lanes:
+	//   1. thread = one core column of one (level, row-phase) slice: threshold, then the four direct neighbours (most pixels above the
+	//      threshold lose against one of them); what is left (a few per cent) is compacted into a workgroup-wide list;
+	//   2. one listed pixel per thread: frame tests, the full window, the ignore border -> survivor list.
 	{
 		constexpr int SL = 256 / G::ITW;           // row slices a pass of 256 threads covers (ITW lanes per row)
 		const int px = tid & (G::ITW - 1), slice = tid / G::ITW;
-		const int x = x0 + px;
 		for (int row = slice; row < P.nmid * G::TY && !BHIP_ABLATE(P, 2); row += SL) {
 			const int m = row / G::TY, py = row - m * G::TY;
 			if (px >= G::TX) continue;
 			const float* mid = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
 			const float val = mid[0];
 			if (!(val >= P.threshold) || val == FLT_MAX) continue;
+			const float n0 = mid[-1], n1 = mid[1], n2 = mid[-G::ITp], n3 = mid[G::ITp];
+			if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) continue;
+			// a pixel above its four direct neighbours has none of them in the list: at most every second pixel, NCAND holds them all
+			candList[atomicAdd(candCount, 1)] = (unsigned short)((m << 12) | (py << 6) | px);
+		}
+	}
+	__syncthreads();
+	{
+		const int ncand = *candCount;
+		for (int ci = tid; ci < ncand; ci += 256) {
+			const int cc = candList[ci];
+			const int m = cc >> 12, py = (cc >> 6) & 63, px = cc & 63;
+			const int code = (m << 16) | (py << 8) | px;
+			const float* mid = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
+			const float val = mid[0];
 			const int b = m == 0 ? M0.border : M1.border;
-			const int y = y0 + py;
+			const int x = x0 + px, y = y0 + py;
 			if (x < b || x >= P.w - b || y < b || y >= P.h - b) continue;
-			// most pixels above the threshold lose against a direct neighbour: four reads settle them before the full window is fetched
-			{
-				const float n0 = mid[-1], n1 = mid[1], n2 = mid[-G::ITp], n3 = mid[G::ITp];
-				if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) continue;
-			}
 			bool isMax = true;
 #pragma unroll
 			for (int j = -R; j <= R; j++)
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			if (x < ignoreR || x >= P.w - ignoreR || y < ignoreR || y >= P.h - ignoreR) continue;
 			// two strict (2R+1)^2 maxima are more than R apart: at most one per (R+1)^2 block, SURV = 2 * blocks per tile holds them all
 			const int slot = atomicAdd(survCount, 1);
-			if (slot < G::SURV) survList[slot] = (m << 16) | (py << 8) | px;
+			if (slot < G::SURV) survList[slot] = code;
 		}
 	}
 	__syncthreads();
