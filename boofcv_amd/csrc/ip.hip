@@ -77,8 +77,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 	const int offL = P.koff, offR = P.kw - P.koff - 1;
 	if (P.borderOnly) {
 		// border fix-up after a streaming kernel: index t of the filtered axis runs over the offL leading and offR trailing positions
+		// (horizontal: the grid is flat, consecutive threads take the border columns of one row, then the next row)
+		const int nb = offL + offR;
+		if (!VERTICAL) {
+			if (nb <= 0) return;
+			y = x / nb;
+			x -= y * nb;
+			if (y >= P.height) return;
+		}
 		int& t = VERTICAL ? y : x;
-		if (t >= offL + offR) return;
+		if (t >= nb) return;
 		t = t < offL ? t : extent - offR + (t - offL);
 	}
 	if (x >= P.width) return;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void k_conv_v_tile(ConvParams P) {
 // ---- streaming forms for the reference's unrolled widths (3..11, centred): no LDS, every input row loaded once per strip ----
 // Horizontal: lane l owns columns 4l..4l+3 of a 256-column strip and walks CS_ROWS rows; a row's taps are NL aligned 16-byte loads
 // (own chunk + the chunks the kernel reaches into; neighbouring lanes' chunks are L1 hits), results leave as one 16-byte store.
-#define CS_ROWS 16
+#define CS_ROWS 8
 template <int KW>
 __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 	constexpr int R = KW / 2, NC = (R + 3) / 4, NL = 1 + 2 * NC, PL = 4 * NC;
@@ -261,6 +269,54 @@ __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 	// NB row buffers take turns: while row y is filtered and stored, the chunks of the next NB - 1 rows are in flight (a wave has to keep
 	// several KB on the way to cover the HBM latency at 8 waves per SIMD)
 	constexpr int NB = KW <= 5 ? 4 : (KW <= 7 ? 3 : 2);
+	if constexpr (NC == 1) {
+		// kernels that reach at most one chunk to either side: every lane loads its own chunk only and receives the neighbours' chunks by
+		// lane shifts; the strip's first / last lane fetch the chunk beyond the strip themselves (one extra 16-byte request per row and side)
+		float4 own[NB], edge[NB];
+		const bool first = lane == 0, last = lane == 63;
+		auto fetch = [&](float4& own, float4& edge, int y) {
+			if (y < yEnd) {
+				const float* row = img + (long long)y * P.inStride;
+				own = loadRow4(row, x, P.width);
+				if (first) edge = loadRow4(row, x - 4, P.width);
+				if (last) edge = loadRow4(row, x + 4, P.width);
+			}
+		};
+		auto emit = [&](const float4& own, const float4& edge, int y) {
+			if (y >= yEnd) return;   // wave-uniform
+			float4 lf, rt;
+			lf.x = __shfl_up(own.x, 1, 64); lf.y = __shfl_up(own.y, 1, 64); lf.z = __shfl_up(own.z, 1, 64); lf.w = __shfl_up(own.w, 1, 64);
+			rt.x = __shfl_down(own.x, 1, 64); rt.y = __shfl_down(own.y, 1, 64); rt.z = __shfl_down(own.z, 1, 64); rt.w = __shfl_down(own.w, 1, 64);
+			if (first) lf = edge;
+			if (last) rt = edge;
+			const float v[12] = {lf.x, lf.y, lf.z, lf.w, own.x, own.y, own.z, own.w, rt.x, rt.y, rt.z, rt.w};
+			float r[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				float total = v[PL - R + j] * P.k[0];
+#pragma unroll
+				for (int i = 1; i < KW; i++) total += v[PL - R + j + i] * P.k[i];
+				r[j] = total;
+			}
+			float* dst = outImg + (long long)y * P.outStride + x;
+			if (allInterior) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+			else {
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					if (x + j >= R && x + j < P.width - R) dst[j] = r[j];
+			}
+		};
+#pragma unroll
+		for (int q = 0; q < NB; q++) fetch(own[q], edge[q], y0 + q);
+		for (int y = y0; y < yEnd; y += NB) {
+#pragma unroll
+			for (int q = 0; q < NB; q++) {
+				emit(own[q], edge[q], y + q);
+				fetch(own[q], edge[q], y + q + NB);
+			}
+		}
+		return;
+	}
 	float4 buf[NB][NL];
 	auto fetch = [&](float4 (&buf)[NL], int y) {
 		if (y < yEnd) {
@@ -304,7 +360,7 @@ __global__ __launch_bounds__(256) void k_conv_h_stream(ConvParams P) {
 // Vertical: lane l owns columns 4l..4l+3 and walks a strip of CS_ROWS_V output rows with the KW input rows of the current output in a
 // register ring of KW+PF slots (the extra slots receive the rows of the next PF outputs while the current one is computed).  Strips that touch the top or
 // bottom border evaluate the border rules per row from the same ring.
-#define CS_ROWS_V 32
+#define CS_ROWS_V 16
 template <int KW>
 __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
 	constexpr int PF = KW <= 5 ? 3 : 2;        // rows requested ahead of the output being computed
@@ -410,7 +466,7 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 			// the kw - 1 border columns (rows) with the re-normalised formula: a thin launch of the general kernel
 			P.borderOnly = 1;
 			if (vertical) hipLaunchKernelGGL(k_conv<true>, dim3((width + 255) / 256, kw - 1, batch), dim3(256), 0, ctx->stream, P);
-			else hipLaunchKernelGGL(k_conv<false>, dim3(1, height, batch), dim3(256), 0, ctx->stream, P);
+			else hipLaunchKernelGGL(k_conv<false>, dim3((unsigned)(((long long)height * (kw - 1) + 255) / 256), 1, batch), dim3(256), 0, ctx->stream, P);
 		}
 	} else if (vertical) {
 		dim3 grid((width + CT_W - 1) / CT_W, (height + CV_ROWS - 1) / CV_ROWS, batch);

@@ -58,6 +58,15 @@ def main():
                 rows.append(r)
                 print(json.dumps(r), flush=True)
 
+        # the device's own ceiling for one read + one write stream of this size: torch's copy kernel, timed with events on the same stream
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            dst.copy_(src)
+        ev0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        ev1.record(); torch.cuda.synchronize()
+        emit("device copy (torch, 4P read + 4P write)", {"copy": (ev0.elapsed_time(ev1) / 10, 8.0 * B * H * W)})
         for r in (2, 5, 20):
             k = api.FactoryKernelGaussian.gaussian1D_F32(-1, r).data
             emit("conv_norm_h r=%d" % r, run(ctx, lambda: ops.convolveNormalizedHorizontal(k, r, src, dst), 10))
