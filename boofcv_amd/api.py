@@ -482,9 +482,12 @@ class DetectDescribePoint:
             self._cache[image] = (xys, ang, white, desc)
         return self._cache[image]
 
-    def fetchAll(self):
+    def fetchAll(self, out=None):
         """The whole batch of the last detect in one set of copies (bhip_surf_fetch_all): (xy_scale [total,3], angle [total],
-        white [total], desc [total,dof], starts [batch+1]); image i owns rows starts[i]:starts[i+1]."""
+        white [total], desc [total,dof], starts [batch+1]); image i owns rows starts[i]:starts[i+1].
+        out = (xy_scale, angle, white, desc) receives the copies when given: C-contiguous float64 / uint8 arrays with at least `total` rows
+        (e.g. views of page-locked memory a caller keeps across batches -- the copies then run at PCIe speed); views of the first `total`
+        rows are returned."""
         L = _lib.load()
         counts = np.zeros(self._batch, dtype=np.int32)
         n = C.c_int(0)
@@ -493,7 +496,15 @@ class DetectDescribePoint:
             counts[i] = n.value
         starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         total = int(starts[-1])
-        xys = np.zeros((total, 3)); ang = np.zeros(total); white = np.zeros(total, dtype=np.uint8); desc = np.zeros((total, self._dof))
+        if out is None:
+            xys = np.empty((total, 3)); ang = np.empty(total); white = np.empty(total, dtype=np.uint8); desc = np.empty((total, self._dof))
+        else:
+            xys, ang, white, desc = out
+            want = ((xys, np.float64, (3,)), (ang, np.float64, ()), (white, np.uint8, ()), (desc, np.float64, (self._dof,)))
+            for a, dt, tail in want:
+                if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous and a.shape[1:] == tail and a.shape[0] >= total):
+                    raise IllegalArgumentException("fetchAll: output arrays must be C-contiguous, of the right type and at least %d rows long" % total)
+            xys, ang, white, desc = xys[:total], ang[:total], white[:total], desc[:total]
         if total:
             _check(self.ctx, L.bhip_surf_fetch_all(self._h, xys.ctypes.data_as(_lib._dp), ang.ctypes.data_as(_lib._dp), white.ctypes.data_as(_lib._u8p),
                                                    desc.ctypes.data_as(_lib._dp)))

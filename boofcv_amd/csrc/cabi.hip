@@ -408,6 +408,11 @@ struct bhip_surf {
 	DescPlanar planar{};
 	bool descOptions = false;  // the last detect needs `planar` passed to the describe kernel (colour bands and / or integer taps)
 	int dofOut() const { return tables.dof * (planarBands > 0 ? planarBands : 1); }
+	// host-frame batches are processed in chunks so that the upload of chunk k+1 (copy stream) runs under the kernels of chunk k: the
+	// chunks go through `worker` (same configuration, chunk-sized work buffers), whose results are appended to this object's arrays
+	bhip_surf* worker = nullptr;
+	hipStream_t copyStream = nullptr;
+	float* extII = nullptr;    // worker only: where the integral images of the current chunk go (a slice of the owner's iiBuf)
 };
 
 static int buildTables(bhip_surf* s) {
@@ -477,15 +482,19 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, boo
 	s->det.intTaps = u8;
 	BHIP_TRY(s->det.prepare(ctx, W, H, batch));
 	const int nImages = planarBands > 0 ? 1 + planarBands : batch;
-	BHIP_TRY(s->iiBuf.reserve(ctx, (size_t)W * H * 4 * nImages));
+	float* iiBase = s->extII;
+	if (!iiBase) {
+		BHIP_TRY(s->iiBuf.reserve(ctx, (size_t)W * H * 4 * nImages));
+		iiBase = s->iiBuf.as<float>();
+	}
 	s->W = W; s->H = H; s->batch = batch;
-	ImgViewW iiW{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
-	if (u8) BHIP_TRY(bhip_launch_integral_u8(ctx, (const unsigned char*)in.data, (long long)W * H, W, s->iiBuf.as<int>(), (long long)W * H, W, W, H, nImages));
+	ImgViewW iiW{iiBase, (long long)W * H, W, W, H};
+	if (u8) BHIP_TRY(bhip_launch_integral_u8(ctx, (const unsigned char*)in.data, (long long)W * H, W, (int*)iiBase, (long long)W * H, W, W, H, nImages));
 	else BHIP_TRY(bhip_launch_integral(ctx, in, iiW, nImages));
-	ImgView ii{s->iiBuf.as<float>(), (long long)W * H, W, W, H};
+	ImgView ii{iiBase, (long long)W * H, W, W, H};
 	s->iiView = ii;
 	s->planarBands = planarBands;
-	s->planar = DescPlanar{s->iiBuf.as<float>() + (long long)W * H, (long long)W * H * (1 + planarBands), (long long)W * H, planarBands,
+	s->planar = DescPlanar{iiBase + (long long)W * H, (long long)W * H * (1 + planarBands), (long long)W * H, planarBands,
 						   planarBands > 0 ? 1.0 : 2.0, u8};
 	s->descOptions = planarBands > 0 || u8;
 	BHIP_TRY(s->det.run(ctx, ii));
@@ -526,6 +535,119 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, boo
 	return BHIP_OK;
 }
 
+extern "C" int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out);
+
+// device buffer growth that keeps the first `keep` bytes (result arrays that chunks are appended to)
+static int growKeep(bhip_ctx* ctx, DevBuf& b, size_t bytes, size_t keep) {
+	if (bytes <= b.cap) return BHIP_OK;
+	DevBuf n;
+	BHIP_TRY(n.reserve(ctx, bytes + bytes / 4));
+	if (b.p && keep) BHIP_HIP(ctx, hipMemcpyAsync(n.p, b.p, keep, hipMemcpyDeviceToDevice, ctx->stream));
+	if (b.p) { BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream)); b.release(); }
+	b = n;
+	return BHIP_OK;
+}
+
+#define SURF_CHUNK 32   // frames per chunk of a host batch (265 MB of 1080p GrayF32: ~5 ms of PCIe, ~3 ms of kernels)
+
+// Host frames -> device in chunks on the copy stream, each chunk detected + described by the worker object as soon as it has arrived;
+// results are appended to the owner's arrays, which end up exactly as one surfRun over the whole batch leaves them.
+// upload(i, dst, stream) enqueues the copy of frame i.  Returns BHIP_OK with *done = false when the batch has to go through the plain
+// path (small batch, or a key-point list outgrew the owner's capacity half way).
+template <class Upload>
+static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t imgBytes, bool u8, Upload upload, bool* done) {
+	bhip_ctx* ctx = s->ctx;
+	*done = false;
+	int chunk = SURF_CHUNK;
+	{ const char* e = getenv("BHIP_SURF_CHUNK"); if (e && atoi(e) > 0) chunk = atoi(e); }   // tests: chunk small batches too
+	if (batch < 2 * chunk) return BHIP_OK;
+	if (!s->worker) {
+		BHIP_TRY(bhip_surf_create(ctx, &s->det.cfg, &s->sd, &s->ori, s->stable, &s->worker));
+		BHIP_HIP(ctx, hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking));
+	}
+	bhip_surf* w = s->worker;
+	const size_t px = (size_t)width * height;
+	s->haveResult = false;
+	s->det.intTaps = u8;
+	BHIP_TRY(s->det.prepare(ctx, width, height, batch));
+	BHIP_TRY(s->iiBuf.reserve(ctx, px * 4 * batch));
+	// everything queued on the compute stream so far (an earlier batch may still read inBuf) precedes the first upload
+	hipEvent_t ev;
+	BHIP_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	BHIP_HIP(ctx, hipEventRecord(ev, ctx->stream));
+	BHIP_HIP(ctx, hipStreamWaitEvent(s->copyStream, ev, 0));
+	const int nchunks = (batch + chunk - 1) / chunk;
+	std::vector<hipEvent_t> arrived(nchunks, nullptr);
+	int status = BHIP_OK;
+	for (int c = 0; c < nchunks && status == BHIP_OK; c++) {
+		const int a = c * chunk, n = std::min(chunk, batch - a);
+		for (int i = a; i < a + n && status == BHIP_OK; i++) status = upload(i, (char*)s->inBuf.p + imgBytes * i, s->copyStream);
+		if (status == BHIP_OK && (hipEventCreateWithFlags(&arrived[c], hipEventDisableTiming) != hipSuccess || hipEventRecord(arrived[c], s->copyStream) != hipSuccess))
+			status = bhip_fail(ctx, BHIP_ERR_HIP, "event");
+	}
+	const int dof = s->tables.dof;
+	s->starts.assign(batch + 1, 0);
+	s->det.counts.assign(batch, 0);
+	long long total = 0;
+	bool fits = true;
+	for (int c = 0; c < nchunks && status == BHIP_OK && fits; c++) {
+		const int a = c * chunk, n = std::min(chunk, batch - a);
+		if (hipStreamWaitEvent(ctx->stream, arrived[c], 0) != hipSuccess) { status = bhip_fail(ctx, BHIP_ERR_HIP, "wait"); break; }
+		w->extII = s->iiBuf.as<float>() + px * a;
+		ImgView in{(const float*)((const char*)s->inBuf.p + imgBytes * a), (long long)px, width, width, height};   // u8: only pointer and shape are used
+		status = surfRun(w, in, n, 0, u8);
+		if (status != BHIP_OK) break;
+		int maxCount = 0;
+		for (int i = 0; i < n; i++) maxCount = std::max(maxCount, w->det.counts[i]);
+		if (maxCount > s->det.cap) { fits = false; break; }   // the owner's [image][cap] key-point array is too narrow: plain path (it grows there)
+		const long long ct = w->det.total;
+		status = growKeep(ctx, s->angBuf, (size_t)std::max<long long>(total + ct, 1) * 8, (size_t)total * 8);
+		if (status == BHIP_OK) status = growKeep(ctx, s->descBuf, (size_t)std::max<long long>(total + ct, 1) * 8 * dof, (size_t)total * 8 * dof);
+		if (status == BHIP_OK) status = growKeep(ctx, s->whiteBuf, (size_t)std::max<long long>(total + ct, 1), (size_t)total);
+		if (status != BHIP_OK) break;
+		hipError_t e = hipSuccess;
+		if (maxCount > 0)
+			e = hipMemcpy2DAsync(s->det.sorted.as<KeyPoint>() + (long long)a * s->det.cap, (size_t)s->det.cap * sizeof(KeyPoint), w->det.sorted.p,
+								 (size_t)w->det.cap * sizeof(KeyPoint), (size_t)maxCount * sizeof(KeyPoint), n, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && ct > 0) e = hipMemcpyAsync(s->angBuf.as<double>() + total, w->angBuf.p, (size_t)ct * 8, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && ct > 0) e = hipMemcpyAsync(s->descBuf.as<double>() + total * dof, w->descBuf.p, (size_t)ct * 8 * dof, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && ct > 0) e = hipMemcpyAsync(s->whiteBuf.as<uint8_t>() + total, w->whiteBuf.p, (size_t)ct, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e != hipSuccess) { status = bhip_fail(ctx, BHIP_ERR_HIP, hipGetErrorString(e)); break; }
+		for (int i = 0; i < n; i++) {
+			s->det.counts[a + i] = w->det.counts[i];
+			s->starts[a + i + 1] = s->starts[a + i] + w->det.counts[i];
+		}
+		total += ct;
+	}
+	// every upload has to be over before the caller's frames may change (and before the plain path re-uses inBuf)
+	(void)hipStreamSynchronize(s->copyStream);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (int c = 0; c < nchunks; c++)
+		if (arrived[c]) (void)hipEventDestroy(arrived[c]);
+	(void)hipEventDestroy(ev);
+	w->extII = nullptr;
+	if (status != BHIP_OK) return status;
+	if (!fits) {
+		// the frames are all on the device: run the whole batch the plain way (its detector grows the key-point capacity as needed)
+		ImgView in{s->inBuf.as<float>(), (long long)px, width, width, height};
+		*done = true;
+		return surfRun(s, in, batch, 0, u8);
+	}
+	if (total > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_CAPACITY, "more than 2^31 key points in one batch");
+	s->det.total = total;
+	s->W = width; s->H = height; s->batch = batch;
+	s->iiView = ImgView{s->iiBuf.as<float>(), (long long)px, width, width, height};
+	s->planarBands = 0;
+	s->planar = DescPlanar{s->iiBuf.as<float>() + (long long)px, (long long)px, (long long)px, 0, 2.0, u8};
+	s->descOptions = u8;
+	BHIP_TRY(s->startBuf.reserve(ctx, (size_t)(batch + 1) * 4));
+	BHIP_HIP(ctx, hipMemcpyAsync(s->startBuf.p, s->starts.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	s->haveResult = true;
+	*done = true;
+	return BHIP_OK;
+}
+
 extern "C" {
 
 int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out) {
@@ -548,6 +670,8 @@ int bhip_surf_destroy(bhip_surf* s) {
 	if (!s) return BHIP_OK;
 	(void)hipSetDevice(s->ctx->device);
 	(void)hipStreamSynchronize(s->ctx->stream);
+	if (s->worker) { (void)bhip_surf_destroy(s->worker); s->worker = nullptr; }
+	if (s->copyStream) { (void)hipStreamDestroy(s->copyStream); s->copyStream = nullptr; }
 	s->det.release();
 	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite, &s->permBuf};
 	for (DevBuf* b : bufs) b->release();
@@ -573,15 +697,20 @@ int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* start
 	if (!img || width <= 0 || height <= 0 || batch <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image batch");
 	const size_t imgBytes = (size_t)width * height * 4;
 	BHIP_TRY(s->inBuf.reserve(ctx, imgBytes * batch));
-	for (int i = 0; i < batch; i++) {
+	for (int i = 0; i < batch; i++)
+		if (!img[i] || (stride ? stride[i] : width) < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
+	auto upload = [&](int i, void* dst, hipStream_t st_) -> int {
 		const int st = stride ? stride[i] : width;
-		if (!img[i] || st < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
 		const float* src = img[i] + (startIndex ? startIndex[i] : 0);
 		// a dense frame is one linear copy (the 2-D form is several times slower over PCIe even when pitch == width)
-		if (st == width) BHIP_HIP(ctx, hipMemcpyAsync((char*)s->inBuf.p + imgBytes * i, src, imgBytes, hipMemcpyHostToDevice, ctx->stream));
-		else BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width * 4, src, (size_t)st * 4, (size_t)width * 4, height,
-											hipMemcpyHostToDevice, ctx->stream));
-	}
+		if (st == width) BHIP_HIP(ctx, hipMemcpyAsync(dst, src, imgBytes, hipMemcpyHostToDevice, st_));
+		else BHIP_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)width * 4, src, (size_t)st * 4, (size_t)width * 4, height, hipMemcpyHostToDevice, st_));
+		return BHIP_OK;
+	};
+	bool done = false;
+	BHIP_TRY(surfRunChunked(s, width, height, batch, imgBytes, false, upload, &done));
+	if (done) return BHIP_OK;
+	for (int i = 0; i < batch; i++) BHIP_TRY(upload(i, (char*)s->inBuf.p + imgBytes * i, ctx->stream));
 	ImgView in{s->inBuf.as<float>(), (long long)width * height, width, width, height};
 	return surfRun(s, in, batch);
 }
@@ -617,13 +746,19 @@ int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* star
 	if (!img || width <= 0 || height <= 0 || batch <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image batch");
 	const size_t imgBytes = (size_t)width * height;
 	BHIP_TRY(s->inBuf.reserve(ctx, imgBytes * batch));
-	for (int i = 0; i < batch; i++) {
+	for (int i = 0; i < batch; i++)
+		if (!img[i] || (stride ? stride[i] : width) < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
+	auto upload = [&](int i, void* dst, hipStream_t st_) -> int {
 		const int st = stride ? stride[i] : width;
-		if (!img[i] || st < width) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad image (null or stride < width)");
 		const uint8_t* src = img[i] + (startIndex ? startIndex[i] : 0);
-		if (st == width) BHIP_HIP(ctx, hipMemcpyAsync((char*)s->inBuf.p + imgBytes * i, src, imgBytes, hipMemcpyHostToDevice, ctx->stream));
-		else BHIP_HIP(ctx, hipMemcpy2DAsync((char*)s->inBuf.p + imgBytes * i, (size_t)width, src, (size_t)st, (size_t)width, height, hipMemcpyHostToDevice, ctx->stream));
-	}
+		if (st == width) BHIP_HIP(ctx, hipMemcpyAsync(dst, src, imgBytes, hipMemcpyHostToDevice, st_));
+		else BHIP_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)width, src, (size_t)st, (size_t)width, height, hipMemcpyHostToDevice, st_));
+		return BHIP_OK;
+	};
+	bool done = false;
+	BHIP_TRY(surfRunChunked(s, width, height, batch, imgBytes, true, upload, &done));
+	if (done) return BHIP_OK;
+	for (int i = 0; i < batch; i++) BHIP_TRY(upload(i, (char*)s->inBuf.p + imgBytes * i, ctx->stream));
 	ImgView in{s->inBuf.as<float>(), (long long)width * height, width, width, height};   // only the pointer and the shape are used
 	return surfRun(s, in, batch, 0, true);
 }

@@ -1195,3 +1195,42 @@ def test_batch_level_fetch_and_resident_association(api, orc):
         dd.associateImages([0, 0], [1, 2])       # an image may be the source of one problem per call
     with pytest.raises(api.IllegalArgumentException):
         dd.associateImages([0], [7])
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_chunked_host_batch_equals_plain(api, orc, tmp_path, u8):
+    """bhip_surf_detect_f32 / _u8 process large host batches in chunks (upload of chunk k+1 under the kernels of chunk k, results appended).
+    A 7-frame batch is far below the chunking threshold, so a child process with BHIP_SURF_CHUNK=2 (chunks 2,2,2,1) is compared, array by
+    array, with the plain path of this process and with the oracle."""
+    import os, subprocess, sys
+    frames = []
+    for k in range(7):
+        g = orc.noise_image(200, 150, 300 + k, 0, 255).array().astype(np.float32)
+        frames.append(np.floor(g).astype(np.uint8) if u8 else g)
+    np.save(tmp_path / "frames.npy", np.stack(frames))
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayU8 if u8 else api.GrayF32)
+    Img = api.GrayU8 if u8 else api.GrayF32
+    dd.detectBatch([Img(200, 150, f.reshape(-1)) for f in frames])
+    base = dd.fetchAll()
+    pairs, fit = dd.associateImages(np.arange(7), (np.arange(7) + 1) % 7)
+    assert base[4][-1] > 300
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from boofcv_amd import api; fr = np.load(%r); u8 = %r; "
+            "Img = api.GrayU8 if u8 else api.GrayF32; dd = api.FactoryDetectDescribe.surfStable(None, None, None, Img); "
+            "dd.detectBatch([Img(200, 150, f.reshape(-1)) for f in fr]); o = dd.fetchAll(); "
+            "p, f = dd.associateImages(np.arange(7), (np.arange(7) + 1) %% 7); "
+            "np.savez(%r, xys=o[0], ang=o[1], white=o[2], desc=o[3], starts=o[4], pairs=p, fit=f, one=dd._results(5)[3])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "chunked.npz")
+    e = dict(os.environ); e["BHIP_SURF_CHUNK"] = "2"
+    subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "frames.npy"), u8, out)], check=True, env=e, timeout=300)
+    got = np.load(out)
+    for k, name in enumerate(["xys", "ang", "white", "desc", "starts"]):
+        assert np.array_equal(got[name], base[k]), name
+    assert np.array_equal(got["pairs"], pairs) and np.array_equal(got["fit"], fit)
+    assert np.array_equal(got["one"], dd._results(5)[3])   # per-image fetch after a chunked detect
+    if not u8:   # and the oracle, frame 3
+        ref = orc.Surf(True)
+        ref.detect(orc.Gray.from_array(frames[3]), threads=4)
+        rp = ref.fetch()
+        s0, s1 = int(base[4][3]), int(base[4][4])
+        assert np.array_equal(base[0][s0:s1], rp[0]) and np.array_equal(base[2][s0:s1], rp[2])
