@@ -9,12 +9,14 @@
 // fp16 (v_mfma_f32_32x32x16_f16, 16x the fp32 matrix rate) on descriptors scaled by one power of two 2^-q per call so that the largest
 // squared norm lies in [1/4, 1):
 //     a^ = fl16(2^-q a),  n_a = |2^-q a|^2 (fp32, rounded up) = hi + lo (two fp16),
-//     d~(i,j) = n_a + n_b - 2 <a^_i, b^_j>     -- ONE K = 80 contraction: the row holds [-2 a^ | hi lo 1 1 | 0...], the column [b^ | 1 1 hi lo | 0...]
+//     d~(i,j) = 1 + n_a + n_b - 2 <a^_i, b^_j> -- ONE K = 80 contraction: the row holds [-2 a^ | hi lo 1 1 1 | 0...], the column [b^ | 1 1 hi lo 1 | 0...]
+//   (the constant 1 keeps every score a positive float, so minima are unsigned-integer minima of the bit patterns: v_min3_u32, no NaN
+//    canonicalisation, LDS / global atomicMin on the raw bits)
 // Error bound (u = 2^-11, s = 2^-25 fp16 subnormal half-spacing, |a'|,|b'| < 1 after scaling; products of fp16 are exact in fp32):
 //     input rounding   2[(2u + u^2)|a'||b'| + 8s(1+u)(|a'|+|b'|) + 64 s^2]   <= 9.78e-4 (n_a + n_b) + 1e-6     (double rounding f64->f32->f16: + 2^-24 rel.)
 //     norm split       2^-22 (n_a + n_b) + 2^-24 ;  norm round-up 4 * 2^-24 (n_a + n_b)
-//     fp32 accumulate  85 additions, <= 2^-23 relative each even if truncating: 2^-16 (n_a + n_b + 2|a'||b'|) <= 2^-15 (n_a + n_b)
-//   =>  |d~ - d'| <= eps(i,j) = C16 (n_a + n_b) + ABS16,   C16 = 1.03e-3,  ABS16 = 2e-6   (d' = 2^-2q d, the exact scaled distance)
+//     fp32 accumulate  85 additions, <= 2^-23 relative each even if truncating: 2^-16 (1 + n_a + n_b + 2|a'||b'|) <= 2^-15 (n_a + n_b) + 1.6e-5
+//   =>  |d~ - 1 - d'| <= eps(i,j) = C16 (n_a + n_b) + ABS16,   C16 = 1.03e-3,  ABS16 = 2e-5   (d' = 2^-2q d, the exact scaled distance)
 // Pass 1 reduces d~ to per-row and per-column minima.  Pass 2 recomputes the tiles (same instructions, same bits) and lists every pair with
 //     d~(i,j) <= rowmin~(i) + band(i)   /   d~(i,j) <= colmin~(j) + band(j),     band = 2 (C16 (n + max n) + ABS16)   (>= 2 eps)
 // The true row arg-min (and every exact tie of it) and the true column minimum (and every exact tie) are provably inside those lists and
@@ -49,7 +51,7 @@ struct AssocCand {
 };
 
 #define C16 1.03e-3f
-#define ABS16 2.0e-6f
+#define ABS16 2.0e-5f
 #define BIG16 60000.0f     // "norm" of a row / column that does not exist: its scores can never pass a threshold (real norms are < 1)
 #define ROW_CHUNKS 9       // uint4 per stored row
 #define BLOCK_ROWS 256     // 4 waves x 64 rows
@@ -62,13 +64,6 @@ __device__ __forceinline__ void waveSyncLds() {
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ unsigned int fkey(float f) {
-	const unsigned int b = __float_as_uint(f);
-	return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float fkeyInv(unsigned int k) {
-	return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
 // q with max norm * 2^-2q in [1/4, 1)  (0 when there is no positive norm)
 __device__ __forceinline__ int scaleExp(float maxN) {
 	if (!(maxN > 0.0f)) return 0;
@@ -98,7 +93,7 @@ __global__ __launch_bounds__(256) void k_assoc_norms(const double* __restrict__ 
 	}
 }
 
-// ---- fp64 -> scaled fp16 rows [64 values | hi lo 1 1 0 0 0 0]; nrm is rescaled in place ----
+// ---- fp64 -> scaled fp16 rows [64 values | hi lo 1 1 1 0 0 0]; nrm is rescaled in place ----
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_assoc_half(const double* __restrict__ D, long long rows, float* __restrict__ nrm, const int* __restrict__ flags,
 													  _Float16* __restrict__ Hrow) {
@@ -115,7 +110,7 @@ __global__ __launch_bounds__(256) void k_assoc_half(const double* __restrict__ D
 		const float n = ldexpf(nrm[row], -2 * q);
 		const _Float16 hi = (_Float16)n;
 		const _Float16 lo = (_Float16)(n - (float)hi);
-		const h16x8 e = {hi, lo, (_Float16)1.0f, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+		const h16x8 e = {hi, lo, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
 		*(h16x8*)(out + 64) = e;
 		nrm[row] = n;
 	}
@@ -137,11 +132,11 @@ __global__ void k_assoc_thresholds(const AssocProblem* __restrict__ probs, int c
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.ns + P.nd; i += gridDim.x * blockDim.x) {
 		if (i < P.ns) {
 			const float band = 2.0f * (C16 * (nrmS[P.srcOff + i] + maxN) + ABS16);
-			rowThr[P.rowBase + i] = fkeyInv(rowKey[P.rowBase + i]) + band;
+			rowThr[P.rowBase + i] = __uint_as_float(rowKey[P.rowBase + i]) + band;   // still carries the +1 of the scores
 		} else {
 			const int j = i - P.ns;
 			const float band = 2.0f * (C16 * (nrmD[P.dstOff + j] + maxN) + ABS16);
-			colThr[P.colBase + j] = fkeyInv(colKey[P.colBase + j]) + band;
+			colThr[P.colBase + j] = __uint_as_float(colKey[P.colBase + j]) + band;
 		}
 	}
 }
@@ -158,6 +153,9 @@ struct MfmaArgs {
 	AssocCand* cand;
 	int* counter;    // number of listed pairs
 	int cap;
+#ifdef BHIP_EXPERIMENTS
+	int ablate;      // timing experiments only (BHIP_ASSOC_ABLATE): 1 no MFMA, 2 no epilogue, 4 no staging, 8 no barriers
+#endif
 };
 
 #define CAND_LDS 512   // per-wave staging slots in LDS; a 64-row strip lists about 150 pairs per sweep
@@ -199,8 +197,8 @@ __device__ __forceinline__ void candFlush(const MfmaArgs& A, const int2* buf, co
 }
 
 __device__ __forceinline__ h16x8 asHalf8(uint4 v) { return __builtin_bit_cast(h16x8, v); }
-__device__ __forceinline__ uint4 extChunk(float n0, float n1, float n2, float n3) {   // [n0 n1 n2 n3 0 0 0 0] as halves
-	const h16x8 h = {(_Float16)n0, (_Float16)n1, (_Float16)n2, (_Float16)n3, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+__device__ __forceinline__ uint4 extChunk(float n0, float n1, float n2, float n3) {   // [n0 n1 n2 n3 1 0 0 0] as halves
+	const h16x8 h = {(_Float16)n0, (_Float16)n1, (_Float16)n2, (_Float16)n3, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
 	return __builtin_bit_cast(uint4, h);
 }
 
@@ -208,7 +206,8 @@ template <int PASS>
 __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 	// B tiles: [buffer][tile][chunk * 33 + column]; chunk 8 = [1 1 hi lo 0..], chunk 9 = zeros (k = 72..79, read by the upper half-wave)
 	__shared__ uint4 tileB[2][2][10 * 33];
-	__shared__ unsigned int colMin[PASS == 1 ? COL_CAP : 1];
+	__shared__ unsigned int colLds[COL_CAP];          // PASS 1: column minima of this block's rows ; PASS 2: column thresholds (float bits)
+	__shared__ float rowThrLds[PASS == 2 ? BLOCK_ROWS : 4];   // PASS 2: thresholds of the block's rows
 	__shared__ int2 candLds[PASS == 2 ? 4 : 1][PASS == 2 ? CAND_LDS : 1];
 	__shared__ int candCnt[4];
 	const AssocBlock B = A.blocks[blockIdx.x];
@@ -224,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 	if (lane == 0) *candN = 0;   // ordered before first use by the barrier after the first stash
 
 	if (tid < 128) tileB[tid >> 6][(tid >> 5) & 1][9 * 33 + (tid & 31)] = make_uint4(0, 0, 0, 0);
-	if (PASS == 1)
-		for (int c = tid; c < B.col1 - B.col0; c += 256) colMin[c] = 0xFFFFFFFFu;
+	for (int c = tid; c < B.col1 - B.col0; c += 256) colLds[c] = PASS == 1 ? 0xFFFFFFFFu : __float_as_uint(A.colThr[P.colBase + B.col0 + c]);
+	if (PASS == 2) rowThrLds[tid] = B.row0 + tid < P.ns ? A.rowThr[P.rowBase + B.row0 + tid] : -INFINITY;
 
 	// A fragments: tile t, row rowT + 32 t + r; MFMA s (k = 16 s + 8 h ..) reads chunk 2 s + h, the fifth reads chunk 8 / zeros
 	h16x8 a[2][5];
@@ -244,116 +243,133 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 		}
 	}
 	// per accumulator register: C layout row = (reg&3) + 8*(reg>>2) + 4h of the tile, col = lane&31
-	float rowV[2][16];   // PASS 1: running row minimum ; PASS 2: row threshold
+	unsigned int rowM[2][16];     // PASS 1: running row minimum (bit pattern of a positive float)
 #pragma unroll
 	for (int t = 0; t < 2; t++)
 #pragma unroll
-		for (int g = 0; g < 16; g++) {
-			const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-			if (PASS == 1) rowV[t][g] = INFINITY;
-			else rowV[t][g] = rr < P.ns ? A.rowThr[P.rowBase + rr] : -INFINITY;
-		}
+		for (int g = 0; g < 16; g++) rowM[t][g] = 0xFFFFFFFFu;
 
-	// staging: 64 columns x 9 chunks per step, consecutive threads fetch consecutive 16-byte chunks of a row
-	uint4 pre[3];
-	auto fetch = [&](int c0) {
+	// staging: 64 columns x 9 chunks per step, consecutive threads fetch consecutive 16-byte chunks of a row; a thread's three
+	// (column, chunk) slots are fixed for the whole sweep, only the column base moves
+	constexpr int D = 4;   // register sets of staged chunks: a step's loads are issued D steps before they are stored to LDS (L2 latency >> one step)
+	uint4 pre[D][3];
+	int stCl[3], stLds[3];
+	const uint4* stPtr[3];
+	bool stOn[3], stExt[3];
+#pragma unroll
+	for (int q = 0; q < 3; q++) {
+		const int g = tid + 256 * q;
+		const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
+		stOn[q] = g < 64 * ROW_CHUNKS;
+		stCl[q] = cl;
+		stExt[q] = ch == 8;
+		stLds[q] = (cl >> 5) * (10 * 33) + ch * 33 + (cl & 31);
+		stPtr[q] = A.Hd + (long long)(P.dstOff + B.col0 + cl) * ROW_CHUNKS + ch;
+	}
+	auto fetch = [&](uint4 (&pr)[3], int c0) {
 #pragma unroll
 		for (int q = 0; q < 3; q++) {
-			const int g = tid + 256 * q;
-			if (g < 64 * ROW_CHUNKS) {
-				const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
-				const int col = c0 + cl;
+			if (stOn[q]) {
 				uint4 v;
-				if (col < B.col1) {
-					v = A.Hd[(long long)(P.dstOff + col) * ROW_CHUNKS + ch];
-					if (ch == 8) { const unsigned int x = v.x; v.x = v.y; v.y = x; }   // [hi lo | 1 1] -> [1 1 | hi lo]
+				if (c0 + stCl[q] < B.col1) {
+					v = stPtr[q][(long long)(c0 - B.col0) * ROW_CHUNKS];
+					if (stExt[q]) { const unsigned int x = v.x; v.x = v.y; v.y = x; }   // [hi lo | 1 1 | 1 ..] -> [1 1 | hi lo | 1 ..]
 				} else {
-					v = ch == 8 ? extChunk(1.0f, 1.0f, BIG16, 0.0f) : make_uint4(0, 0, 0, 0);
+					v = stExt[q] ? extChunk(1.0f, 1.0f, BIG16, 0.0f) : make_uint4(0, 0, 0, 0);
 				}
-				pre[q] = v;
+				pr[q] = v;
 			}
 		}
 	};
-	auto stash = [&](int buf) {
+	auto stash = [&](int buf, const uint4 (&pr)[3]) {
 #pragma unroll
-		for (int q = 0; q < 3; q++) {
-			const int g = tid + 256 * q;
-			if (g < 64 * ROW_CHUNKS) {
-				const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
-				tileB[buf][cl >> 5][ch * 33 + (cl & 31)] = pre[q];
-			}
-		}
+		for (int q = 0; q < 3; q++)
+			if (stOn[q]) (&tileB[buf][0][0])[stLds[q]] = pr[q];
 	};
-	fetch(B.col0);
-	stash(0);
+#pragma unroll
+	for (int k = 0; k < D; k++) fetch(pre[k], B.col0 + 64 * k);
+	stash(0, pre[0]);
+	fetch(pre[0], B.col0 + 64 * D);
 	__syncthreads();
-	int buf = 0;
-	for (int c0 = B.col0; c0 < B.col1; c0 += 64, buf ^= 1) {
-		const int colA = c0 + r, colB = c0 + 32 + r;
-		const bool okA = colA < B.col1, okB = colB < B.col1;
-		const bool more = c0 + 64 < B.col1;   // block-uniform
-		if (more) fetch(c0 + 64);
-		float tA = -INFINITY, tB = -INFINITY;
-		if (PASS == 2 && live) {
-			if (okA) tA = A.colThr[P.colBase + colA];
-			if (okB) tB = A.colThr[P.colBase + colB];
-		}
-		f32x16 acc[2][2];
-		if (live) {
+	for (int cb = B.col0; cb < B.col1; cb += 64 * D) {
 #pragma unroll
-			for (int t = 0; t < 2; t++)
-#pragma unroll
-				for (int c = 0; c < 2; c++)
-#pragma unroll
-					for (int g = 0; g < 16; g++) acc[t][c][g] = 0.0f;
-#pragma unroll
-			for (int s = 0; s < 5; s++) {
-				const int ch = s < 4 ? 2 * s + h : 8 + h;
-				const h16x8 b0 = asHalf8(tileB[buf][0][ch * 33 + r]);
-				const h16x8 b1 = asHalf8(tileB[buf][1][ch * 33 + r]);
-				acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b0, acc[0][0], 0, 0, 0);
-				acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b0, acc[1][0], 0, 0, 0);
-				acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b1, acc[0][1], 0, 0, 0);
-				acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b1, acc[1][1], 0, 0, 0);
-			}
-		}
-		if (more) stash(buf ^ 1);   // the other buffer was last read before the previous barrier
-		if (live) {
-			if (PASS == 1) {
-				float cA = INFINITY, cB = INFINITY;
+		for (int k = 0; k < D; k++) {   // step k of this round reads LDS buffer k & 1 (D is even) and register set (k + 1) % D feeds the next step
+			const int c0 = cb + 64 * k;
+			if (c0 >= B.col1) break;   // block-uniform
+			const int buf = k & 1;
+			const int colA = c0 + r, colB = c0 + 32 + r;
+			const bool okA = colA < B.col1, okB = colB < B.col1;
+			const bool more = c0 + 64 < B.col1;   // block-uniform
+			f32x16 acc[2][2];
+			if (live) {
 #pragma unroll
 				for (int t = 0; t < 2; t++)
 #pragma unroll
-					for (int g = 0; g < 16; g++) {
-						rowV[t][g] = fminf(rowV[t][g], fminf(acc[t][0][g], acc[t][1][g]));
-						cA = fminf(cA, acc[t][0][g]);
-						cB = fminf(cB, acc[t][1][g]);
-					}
-				cA = fminf(cA, __shfl_xor(cA, 32, 64));
-				cB = fminf(cB, __shfl_xor(cB, 32, 64));
-				if (h == 0) {
-					if (okA) atomicMin(&colMin[colA - B.col0], fkey(cA));
-					if (okB) atomicMin(&colMin[colB - B.col0], fkey(cB));
+					for (int c = 0; c < 2; c++)
+#pragma unroll
+						for (int g = 0; g < 16; g++) acc[t][c][g] = 0.0f;
+#pragma unroll
+				for (int s = 0; s < 5 && !BHIP_ABLATE(A, 1); s++) {
+					const int ch = s < 4 ? 2 * s + h : 8 + h;
+					const h16x8 b0 = asHalf8(tileB[buf][0][ch * 33 + r]);
+					const h16x8 b1 = asHalf8(tileB[buf][1][ch * 33 + r]);
+					acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b0, acc[0][0], 0, 0, 0);
+					acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b0, acc[1][0], 0, 0, 0);
+					acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b1, acc[0][1], 0, 0, 0);
+					acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b1, acc[1][1], 0, 0, 0);
 				}
-			} else {
-#pragma unroll
-				for (int t = 0; t < 2; t++)
-#pragma unroll
-					for (int g = 0; g < 16; g++) {
-						const float dA = acc[t][0][g], dB = acc[t][1][g];
-						const bool rA = dA <= rowV[t][g], rB = dB <= rowV[t][g], qA = dA <= tA, qB = dB <= tB;
-						if (__ballot(rA || rB || qA || qB) != 0ull) {   // wave-uniform, a few times per step
-							const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-							candAdd(A.cand, A.counter, A.cap, candBuf, candN, ((rA || qA) ? 1 : 0) | ((rB || qB) ? 2 : 0), B.p, rr, colA, colB);
-						}
-					}
 			}
+			if (more && !BHIP_ABLATE(A, 4)) {
+				stash(buf ^ 1, pre[(k + 1) % D]);   // the other buffer was last read before the previous barrier
+				fetch(pre[(k + 1) % D], c0 + 64 * (D + 1));
+			}
+			if (live && !BHIP_ABLATE(A, 2)) {
+				if (PASS == 1) {
+					unsigned int cA = 0xFFFFFFFFu, cB = 0xFFFFFFFFu;
+#pragma unroll
+					for (int t = 0; t < 2; t++)
+#pragma unroll
+						for (int g = 0; g < 16; g++) {
+							const unsigned int uA = __float_as_uint(acc[t][0][g]), uB = __float_as_uint(acc[t][1][g]);   // positive floats: bit order == value order
+							rowM[t][g] = min(rowM[t][g], min(uA, uB));
+							cA = min(cA, uA);
+							cB = min(cB, uB);
+						}
+					cA = min(cA, (unsigned int)__shfl_xor((int)cA, 32, 64));
+					cB = min(cB, (unsigned int)__shfl_xor((int)cB, 32, 64));
+					if (h == 0) {
+						if (okA) atomicMin(&colLds[colA - B.col0], cA);
+						if (okB) atomicMin(&colLds[colB - B.col0], cB);
+					}
+				} else {
+					const float tA = okA ? __uint_as_float(colLds[colA - B.col0]) : -INFINITY;
+					const float tB = okB ? __uint_as_float(colLds[colB - B.col0]) : -INFINITY;
+#pragma unroll
+					for (int t = 0; t < 2; t++)
+#pragma unroll
+						for (int j = 0; j < 4; j++) {
+							// rows 8 j + 4 h + 0..3 of tile t = accumulator registers 4 j .. 4 j + 3: one 16-byte LDS read (same address across a half-wave)
+							const float4 rv = *(const float4*)&rowThrLds[64 * wave + 32 * t + 8 * j + 4 * h];
+							const float rthr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								const int g = 4 * j + q;
+								const float dA = acc[t][0][g], dB = acc[t][1][g];
+								const bool rA = dA <= rthr[q], rB = dB <= rthr[q], qA = dA <= tA, qB = dB <= tB;
+								if (__ballot(rA || rB || qA || qB) != 0ull) {   // wave-uniform, a few times per step
+									const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+									candAdd(A.cand, A.counter, A.cap, candBuf, candN, ((rA || qA) ? 1 : 0) | ((rB || qB) ? 2 : 0), B.p, rr, colA, colB);
+								}
+							}
+						}
+				}
+			}
+			if (!BHIP_ABLATE(A, 8)) __syncthreads();
 		}
-		__syncthreads();
 	}
 	if (PASS == 1) {
 		// column minima of this block's rows -> global (one atomic per column per block); the last loop barrier ordered the LDS atomics
-		for (int c = tid; c < B.col1 - B.col0; c += 256) atomicMin(&A.colKey[P.colBase + B.col0 + c], colMin[c]);
+		for (int c = tid; c < B.col1 - B.col0; c += 256) atomicMin(&A.colKey[P.colBase + B.col0 + c], colLds[c]);
 	}
 	if (!live) return;
 	if (PASS == 2) {
@@ -364,11 +380,11 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 		for (int t = 0; t < 2; t++)
 #pragma unroll
 			for (int g = 0; g < 16; g++) {
-				float v = rowV[t][g];
+				unsigned int v = rowM[t][g];
 #pragma unroll
-				for (int o = 16; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+				for (int o = 16; o >= 1; o >>= 1) v = min(v, (unsigned int)__shfl_xor((int)v, o, 64));
 				const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-				if (r == 0 && rr < P.ns) atomicMin(&A.rowKey[P.rowBase + rr], fkey(v));
+				if (r == 0 && rr < P.ns) atomicMin(&A.rowKey[P.rowBase + rr], v);
 			}
 	}
 }
@@ -537,6 +553,9 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	A.Hs = (const uint4*)Hs; A.Hd = (const uint4*)Hd; A.probs = W.probs.as<AssocProblem>(); A.blocks = W.blocks.as<AssocBlock>();
 	A.rowKey = rowKey; A.colKey = colKey; A.rowThr = rowThr; A.colThr = colThr;
 	A.cand = W.cand.as<AssocCand>(); A.counter = counters; A.cap = cap;
+#ifdef BHIP_EXPERIMENTS
+	{ const char* e = getenv("BHIP_ASSOC_ABLATE"); A.ablate = e ? atoi(e) : 0; }
+#endif
 	const unsigned nblocks = (unsigned)blocks.size();
 	{
 		ProfScope ps(ctx, "k_assoc_mfma_pass1", 0, flopsPerPass);

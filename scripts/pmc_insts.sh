@@ -20,3 +20,24 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', 0)):
 PY
 find gpurun_out/pmc_insts -name "*.csv" -size +2M -delete
 cat gpurun_out/pmc_insts/summary.txt
+# matrix-core counters of the association kernels (their own pass: SQ counters per pass are limited)
+echo "pmc mfma: $(date +%T)"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_MFMA SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > gpurun_out/pmc_insts/run_mfma.log 2>&1
+python3 - >> gpurun_out/pmc_insts/summary.txt <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob('gpurun_out/pmc_mfma/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if 'mfma' not in k:
+            continue
+        agg[k.split('(')[0].replace('void ', '')[:48]][r['Counter_Name']] += float(r['Counter_Value'])
+print('matrix-core counters (sums over the launch):')
+for k, v in sorted(agg.items()):
+    busy = v.get('SQ_BUSY_CYCLES', 0)
+    print('%-30s MFMA insts %10.0f  MOPS F16 %12.0f  I8 %12.0f  MFMA busy cycles %12.0f  SQ busy cycles %12.0f  ratio %.3f' % (
+        k, v.get('SQ_INSTS_MFMA', 0), v.get('SQ_INSTS_VALU_MFMA_MOPS_F16', 0), v.get('SQ_INSTS_VALU_MFMA_MOPS_I8', 0), v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0), busy,
+        v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / busy if busy else 0.0))
+PY
+find gpurun_out/pmc_mfma -name "*.csv" -size +2M -delete
+tail -5 gpurun_out/pmc_insts/summary.txt

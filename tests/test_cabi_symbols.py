@@ -68,7 +68,7 @@ def test_shipped_library_has_no_experiment_switches():
     never be able to make a production kernel skip work.  The parity cross-check hooks (UNFUSED, NOSHARE, EXACT, ...) stay."""
     from boofcv_amd import build
     blob = open(build.LIB, "rb").read()
-    for name in (b"BHIP_FUSED_ABLATE", b"BHIP_FUSED_VARIANT", b"BHIP_DESCRIBE_LDSPAD", b"BHIP_DESCRIBE_STAMPS", b"BHIP_DESCRIBE_NOORDER"):
+    for name in (b"BHIP_FUSED_ABLATE", b"BHIP_FUSED_VARIANT", b"BHIP_DESCRIBE_LDSPAD", b"BHIP_DESCRIBE_STAMPS", b"BHIP_DESCRIBE_NOORDER", b"BHIP_ASSOC_ABLATE"):
         assert name not in blob, name
     assert b"BHIP_DETECT_UNFUSED" in blob
 
