@@ -1,5 +1,8 @@
 # dynamic instruction mix per own kernel (rocprofv3 PMC, SQ counters), batch 32
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# synthetic frames are generated once outside the profiler (bench.py BHIP_BENCH_FRAMES_CACHE) and re-read by the profiled runs
+export BHIP_BENCH_FRAMES_CACHE=/tmp/bhip_frames
+python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > /dev/null 2>&1
 rm -rf gpurun_out/pmc_insts && mkdir -p gpurun_out/pmc_insts
 echo "pmc insts: $(date +%T)"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_insts -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > gpurun_out/pmc_insts/run.log 2>&1
