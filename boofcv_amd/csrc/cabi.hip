@@ -254,7 +254,7 @@ struct FhDetector {
 		return allocate(ctx);
 	}
 	int allocate(bhip_ctx* ctx) {
-		size_t intenFloats = 0, expFloats = 0;
+		size_t intenFloats = 0;
 		for (size_t k = 0; k < plan.size(); k++) {
 			FhOctavePlan& o = plan[k];
 			if (!o.fused) {
@@ -262,14 +262,8 @@ struct FhDetector {
 				o.intenOff = intenFloats;
 				intenFloats += (size_t)o.intenImageStride * batch;
 			}
-			if (o.nexport > 0 && k + 1 < plan.size()) {
-				o.expImageStride = (long long)o.nexport * plan[k + 1].w * plan[k + 1].h;
-				o.expOff = expFloats;
-				expFloats += (size_t)o.expImageStride * batch;
-			}
 		}
 		BHIP_TRY(inten.reserve(ctx, intenFloats * 4 + 16));
-		BHIP_TRY(expBuf.reserve(ctx, expFloats * 4 + 16));
 		BHIP_TRY(bitmap.reserve(ctx, (size_t)bitmapWords * 4 * batch));
 		BHIP_TRY(prefix.reserve(ctx, (size_t)bitmapWords * 4 * batch));
 		BHIP_TRY(cand.reserve(ctx, (size_t)cap * sizeof(KeyPoint) * batch));
@@ -297,11 +291,18 @@ struct FhDetector {
 					DetectLevelParams mp[BHIP_MAX_LEVELS];
 					int ml[BHIP_MAX_LEVELS];
 					for (size_t q = 0; q < o.mids.size(); q++) { mp[q] = o.mids[q].p; ml[q] = o.mids[q].level; }
-					FusedExport ex{0, {0, 0}, nullptr, 0, 0, 0};
+					FusedExport ex{0, {0, 0}, nullptr, 0, 0, 0, {0, 0}};
 					if (o.nexport > 0 && k + 1 < plan.size()) {
+						// the shared levels go straight into the consuming octave's level planes: its k_hessian then only recomputes the
+						// pixels the two octaves evaluate with different forms
+						const FhOctavePlan& c = plan[k + 1];
 						ex.n = o.nexport;
 						for (int j = 0; j < o.nlevels; j++) if (o.exportSlot[j] >= 0) ex.level[o.exportSlot[j]] = j;
-						ex.out = expBuf.as<float>() + o.expOff; ex.w = plan[k + 1].w; ex.h = plan[k + 1].h; ex.imageStride = o.expImageStride;
+						ex.out = inten.as<float>() + c.intenOff; ex.w = c.w; ex.h = c.h; ex.imageStride = c.intenImageStride;
+						for (int i = 0; i < c.nlevels; i++) {
+							const int j = c.shareFrom[i];
+							if (j >= 0 && o.exportSlot[j] >= 0) ex.slotOffset[o.exportSlot[j]] = (long long)i * c.w * c.h;
+						}
 					}
 					BHIP_TRY(bhip_launch_detect_fused(ctx, ii, batch, o.skip, o.nlevels, o.sizes, (int)o.mids.size(), mp, ml, cfg.extractRadius,
 													  cfg.detectThreshold, bitmap.as<unsigned int>(), bitmapWords, cand.as<KeyPoint>(), count.as<int>(), cap,
@@ -313,12 +314,12 @@ struct FhDetector {
 				float* base = inten.as<float>() + o.intenOff;
 				HessLevelSource from[BHIP_MAX_LEVELS];
 				for (int i = 0; i < o.nlevels; i++) {
-					from[i] = HessLevelSource{nullptr, 0, 0, 1};
+					from[i] = HessLevelSource{nullptr, 0, 0, 1, 0};
 					const int j = o.shareFrom[i];
 					if (j < 0 || k == 0) continue;
 					const FhOctavePlan& p = plan[k - 1];
-					if (p.fused) from[i] = HessLevelSource{expBuf.as<float>() + p.expOff + (size_t)p.exportSlot[j] * levelStride, p.expImageStride, o.w, 1};
-					else from[i] = HessLevelSource{inten.as<float>() + p.intenOff + (size_t)j * p.w * p.h, p.intenImageStride, p.w, 2};
+					if (p.fused) from[i] = HessLevelSource{base + (size_t)i * levelStride, imageStride, o.w, 1, 1};   // written in place by the fused octave
+					else from[i] = HessLevelSource{inten.as<float>() + p.intenOff + (size_t)j * p.w * p.h, p.intenImageStride, p.w, 2, 0};
 				}
 				unsigned int skipMask = 0;
 				for (int i = 0; i < o.nlevels; i++)

@@ -157,6 +157,7 @@ struct FusedExport {
 	float* out;
 	int w, h;
 	long long imageStride;
+	long long slotOffset[2];   // floats from an image's base to the slot's [h][w] plane (the consuming octave's level planes when it is written in place)
 };
 // where a stand-alone Hessian level comes from: computed, or copied from a level of the same kernel size one octave down
 struct HessLevelSource {
@@ -164,6 +165,7 @@ struct HessLevelSource {
 	long long imageStride;   // floats between images at src
 	int stride;              // floats between rows at src
 	int step;                // 1: src already has this octave's layout, 2: take every second pixel
+	int inPlace;             // src IS this level's output plane (the producer wrote it there): only the pixels that must be recomputed are touched
 };
 int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlevels, const int* sizes, float* intensity, long long levelStride,
 						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr, bool intTaps = false,

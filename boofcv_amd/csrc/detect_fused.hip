@@ -55,6 +55,7 @@ struct FusedParams {
 	float* expOut;
 	int expW, expH;
 	long long expImageStride;
+	long long expSlotOff[2];
 	int ablate;   // timing experiments only (BHIP_FUSED_ABLATE): 1 skip the intensity phase, 2 skip the NMS phase, 4 skip staging
 };
 
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 				else if (lv == 2) v = mid2[(py + R) * G::ITp + (px + R)];
 				else if (lv == 0) v = fusedPixelCall<G, SKIP, 0, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x0 + px, y0 + py, x0, y0, X0, Y0);
 				else v = fusedPixelCall<G, SKIP, 3, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x0 + px, y0 + py, x0, y0, X0, Y0);
-				P.expOut[(long long)img * P.expImageStride + ((long long)k * P.expH + ey) * P.expW + ex] = v;
+				P.expOut[(long long)img * P.expImageStride + P.expSlotOff[k] + (long long)ey * P.expW + ex] = v;
 			}
 		}
 	}
@@ -807,10 +808,11 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 #ifdef BHIP_EXPERIMENTS
 	{ const char* e = getenv("BHIP_FUSED_ABLATE"); P.ablate = e ? atoi(e) : 0; }
 #endif
-	P.nexp = 0; P.expOut = nullptr; P.expW = P.expH = 0; P.expImageStride = 0; P.expLevel[0] = P.expLevel[1] = 0;
+	P.nexp = 0; P.expOut = nullptr; P.expW = P.expH = 0; P.expImageStride = 0; P.expLevel[0] = P.expLevel[1] = 0; P.expSlotOff[0] = P.expSlotOff[1] = 0;
 	if (exp && exp->n > 0) {
 		P.nexp = exp->n; P.expLevel[0] = exp->level[0]; P.expLevel[1] = exp->level[1];
 		P.expOut = exp->out; P.expW = exp->w; P.expH = exp->h; P.expImageStride = exp->imageStride;
+		P.expSlotOff[0] = exp->slotOffset[0]; P.expSlotOff[1] = exp->slotOffset[1];
 	}
 	P.bitmap = bitmap; P.bitmapWords = bitmapWords; P.cand = cand; P.candCount = candCount; P.cap = cap;
 	dim3 grid((P.w + TX - 1) / TX, (P.h + TY - 1) / TY, batch);

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_hessian(HessParams P) {
 		const bool srcInner = px >= bp && px < P.srcW - bp && py >= bp && py < P.srcH - bp;
 		if (srcInner == inner) {
 			const HessLevelSource S = P.from[level];
+			if (S.inPlace) return;   // the producing octave has written this pixel into this very plane
 			P.out[(long long)img * P.imageStrideOut + (long long)level * P.levelStride + (long long)y * P.outStride + x] =
 				S.src[(long long)img * S.imageStride + (long long)(y * S.step) * S.stride + x * S.step];
 			return;
@@ -67,7 +68,7 @@ int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlev
 	P.outStride = outStride;
 	for (int i = 0; i < nlevels; i++) {
 		P.lv[i] = bhipMakeHessLevel(sizes[i], skip);
-		P.from[i] = from ? from[i] : HessLevelSource{nullptr, 0, 0, 1};
+		P.from[i] = from ? from[i] : HessLevelSource{nullptr, 0, 0, 1, 0};
 		P.srcBorder[i] = 0;
 		if (P.from[i].src) {
 			if (skip % 2 != 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "a shared level needs an octave at half the step");
