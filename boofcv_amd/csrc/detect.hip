@@ -125,7 +125,7 @@ struct NmsParams {
 	NmsVirtual virt;
 };
 
-#define VSURV 256     // maxima per pass of k_nms_scalespace that wait for an evaluated outer level (one pass tests 256 candidates)
+#define VSURV 64      // maxima per pass of k_nms_scalespace that wait for an evaluated outer level (such a pass tests 64 candidates)
 #define NMS_ROWS 4   // rows per thread: the column neighbours are shared and the grid has 4x fewer, longer-lived blocks
 __device__ __forceinline__ void emitKeyPoint(const NmsParams& P, int img, int x, int y, KeyPoint kp) {
 	const int b = P.p.border, step = P.radius + 1;
@@ -187,13 +187,14 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 	__shared__ int survXY[VSURV];
 	__shared__ float survVal[VSURV][18];
 	__shared__ int survCount;
-	for (int c0 = 0; c0 < ncand; c0 += blockDim.x) {   // workgroup-uniform trip count
+	const int passN = anyVirtual ? VSURV : (int)blockDim.x;   // candidates per pass: a pass with an evaluated level keeps at most VSURV survivors in LDS
+	for (int c0 = 0; c0 < ncand; c0 += passN) {   // workgroup-uniform trip count
 		if (anyVirtual) {
 			if (threadIdx.x == 0) survCount = 0;
 			__syncthreads();
 		}
 		const int ci = c0 + threadIdx.x;
-		if (ci < ncand) {
+		if ((int)threadIdx.x < passN && ci < ncand) {
 			const int code = candList[ci];
 			const int x = b + blockIdx.x * blockDim.x + (code & 0xFFFF);
 			const int y = yBase + (code >> 16);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void k_nms_scalespace(NmsParams P) {
 								if (nb[k] >= val) alive = false;
 						}
 						if (alive) {
-							const int s = atomicAdd(&survCount, 1);   // <= 256 per pass = VSURV
+							const int s = atomicAdd(&survCount, 1);   // <= passN = VSURV per pass
 							survXY[s] = (y << 16) | x;
 							if (!P.virt.lower.on || !P.virt.upper.on) {
 								const int o = !P.virt.lower.on ? 0 : 9;
