@@ -43,7 +43,7 @@ struct AssocProblem {
 	int rowBase, colBase;         // compact offsets into the per-row / per-column work arrays
 };
 struct AssocBlock {
-	int p, row0, col0, col1;
+	int p, row0, row1, col0, col1;   // rows [row0, row1) x columns [col0, col1) of problem p
 };
 struct AssocCand {
 	int p, i, j, pad;
@@ -54,8 +54,6 @@ struct AssocCand {
 #define ABS16 2.0e-5f
 #define BIG16 60000.0f     // "norm" of a row / column that does not exist: its scores can never pass a threshold (real norms are < 1)
 #define ROW_CHUNKS 9       // uint4 per stored row
-#define BLOCK_ROWS 256     // 4 waves x 64 rows
-#define COL_CAP 4096       // columns one block sweeps at most (its column minima live in LDS)
 
 // LDS writes of one lane visible to the other lanes of the same wave (lock-step wave: only the memory counter has to drain)
 __device__ __forceinline__ void waveSyncLds() {
@@ -154,11 +152,11 @@ struct MfmaArgs {
 	int* counter;    // number of listed pairs
 	int cap;
 #ifdef BHIP_EXPERIMENTS
-	int ablate;      // timing experiments only (BHIP_ASSOC_ABLATE): 1 no MFMA, 2 no epilogue, 4 no staging, 8 no barriers
+	int ablate;      // timing experiments only (BHIP_ASSOC_ABLATE): 1 no MFMA, 2 no per-step epilogue, 4 no A-fragment loads, 16 no row-minimum atomics, 32 no column-minimum flush
 #endif
 };
 
-#define CAND_LDS 512   // per-wave staging slots in LDS; a 64-row strip lists about 150 pairs per sweep
+#define CAND_LDS 256   // per-wave staging slots in LDS (flushed between row tiles when half full; a 64-row tile lists about 25 pairs per strip)
 
 // One list for both directions: a pair listed for its row also updates its column's exact minimum and vice versa, which is harmless (every
 // listed pair is a real pair, and every pair that can attain a row / column minimum is listed).  Hits are rare per lane, so a hit lane
@@ -202,12 +200,17 @@ __device__ __forceinline__ uint4 extChunk(float n0, float n1, float n2, float n3
 	return __builtin_bit_cast(uint4, h);
 }
 
+// B-stationary: a workgroup stages ONE column strip of a problem (<= STRIP_COLS destination rows, fragment order, 5.3 KB per 32 columns)
+// in LDS and then walks its row range in wave tiles of 64 rows -- no barrier and no global traffic inside the sweep except the A fragments
+// of the next tile.  The column minima of the strip accumulate in LDS over all row tiles and leave with one atomic per column.
+#define STRIP_COLS 384
+#define STRIP_TILES (STRIP_COLS / 32)
 template <int PASS>
 __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
-	// B tiles: [buffer][tile][chunk * 33 + column]; chunk 8 = [1 1 hi lo 0..], chunk 9 = zeros (k = 72..79, read by the upper half-wave)
-	__shared__ uint4 tileB[2][2][10 * 33];
-	__shared__ unsigned int colLds[COL_CAP];          // PASS 1: column minima of this block's rows ; PASS 2: column thresholds (float bits)
-	__shared__ float rowThrLds[PASS == 2 ? BLOCK_ROWS : 4];   // PASS 2: thresholds of the block's rows
+	// B tiles: [tile][chunk * 33 + column]; chunk 8 = [1 1 hi lo 1 ..], chunk 9 = zeros (k = 72..79, read by the upper half-wave)
+	__shared__ uint4 tileB[STRIP_TILES][10 * 33];
+	__shared__ unsigned int colLds[STRIP_COLS];       // PASS 1: column minima over this block's rows ; PASS 2: column thresholds (float bits)
+	__shared__ float rowThrLds[PASS == 2 ? 4 : 1][64];   // PASS 2: thresholds of the wave's current 64 rows
 	__shared__ int2 candLds[PASS == 2 ? 4 : 1][PASS == 2 ? CAND_LDS : 1];
 	__shared__ int candCnt[4];
 	const AssocBlock B = A.blocks[blockIdx.x];
@@ -216,176 +219,167 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 	const int tid = threadIdx.x;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 	const int r = lane & 31, h = lane >> 5;
-	const int rowT = B.row0 + 64 * wave;  // first row of this wave's two tiles
-	const bool live = rowT < P.ns;        // a wave without rows still stages B tiles and meets the barriers
+	const int ncol = B.col1 - B.col0;
+	const int ntile = (ncol + 31) >> 5;
 	int2* candBuf = candLds[PASS == 2 ? wave : 0];
 	int* candN = &candCnt[wave];
-	if (lane == 0) *candN = 0;   // ordered before first use by the barrier after the first stash
+	if (lane == 0) *candN = 0;
 
-	if (tid < 128) tileB[tid >> 6][(tid >> 5) & 1][9 * 33 + (tid & 31)] = make_uint4(0, 0, 0, 0);
-	for (int c = tid; c < B.col1 - B.col0; c += 256) colLds[c] = PASS == 1 ? 0xFFFFFFFFu : __float_as_uint(A.colThr[P.colBase + B.col0 + c]);
-	if (PASS == 2) rowThrLds[tid] = B.row0 + tid < P.ns ? A.rowThr[P.rowBase + B.row0 + tid] : -INFINITY;
-
-	// A fragments: tile t, row rowT + 32 t + r; MFMA s (k = 16 s + 8 h ..) reads chunk 2 s + h, the fifth reads chunk 8 / zeros
-	h16x8 a[2][5];
+	// ---- stage the strip: consecutive threads fetch consecutive 16-byte chunks of a destination row (9 per row), four requests per
+	// thread in flight before the first LDS store ----
+	for (int g0 = tid; g0 < ntile * 32 * ROW_CHUNKS; g0 += 4 * 256) {
+		uint4 v[4];
 #pragma unroll
-	for (int t = 0; t < 2; t++) {
-		const int row = rowT + 32 * t + r;
-		if (row < P.ns) {
-			const uint4* src = A.Hs + (long long)(P.srcOff + row) * ROW_CHUNKS;
+		for (int q = 0; q < 4; q++) {
+			const int g = g0 + 256 * q;
+			const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
+			if (g < ntile * 32 * ROW_CHUNKS && cl < ncol) {
+				v[q] = A.Hd[(long long)(P.dstOff + B.col0 + cl) * ROW_CHUNKS + ch];
+				if (ch == 8) { const unsigned int x = v[q].x; v[q].x = v[q].y; v[q].y = x; }   // [hi lo | 1 1 | 1 ..] -> [1 1 | hi lo | 1 ..]
+			} else {
+				v[q] = ch == 8 ? extChunk(1.0f, 1.0f, BIG16, 0.0f) : make_uint4(0, 0, 0, 0);   // a column that does not exist scores > BIG16
+			}
+		}
 #pragma unroll
-			for (int s = 0; s < 4; s++) a[t][s] = asHalf8(src[2 * s + h]) * (_Float16)(-2.0f);
-			a[t][4] = asHalf8(h == 0 ? src[8] : make_uint4(0, 0, 0, 0));
-		} else {
-#pragma unroll
-			for (int s = 0; s < 4; s++) a[t][s] = asHalf8(make_uint4(0, 0, 0, 0));
-			a[t][4] = asHalf8(h == 0 ? extChunk(BIG16, 0.0f, 1.0f, 1.0f) : make_uint4(0, 0, 0, 0));
+		for (int q = 0; q < 4; q++) {
+			const int g = g0 + 256 * q;
+			const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
+			if (g < ntile * 32 * ROW_CHUNKS) tileB[cl >> 5][ch * 33 + (cl & 31)] = v[q];
 		}
 	}
-	// per accumulator register: C layout row = (reg&3) + 8*(reg>>2) + 4h of the tile, col = lane&31
-	unsigned int rowM[2][16];     // PASS 1: running row minimum (bit pattern of a positive float)
-#pragma unroll
-	for (int t = 0; t < 2; t++)
-#pragma unroll
-		for (int g = 0; g < 16; g++) rowM[t][g] = 0xFFFFFFFFu;
+	for (int g = tid; g < ntile * 32; g += 256) tileB[g >> 5][9 * 33 + (g & 31)] = make_uint4(0, 0, 0, 0);
+	for (int c = tid; c < ntile * 32; c += 256)
+		colLds[c] = PASS == 1 ? 0xFFFFFFFFu : (c < ncol ? __float_as_uint(A.colThr[P.colBase + B.col0 + c]) : __float_as_uint(-INFINITY));
+	__syncthreads();
 
-	// staging: 64 columns x 9 chunks per step, consecutive threads fetch consecutive 16-byte chunks of a row; a thread's three
-	// (column, chunk) slots are fixed for the whole sweep, only the column base moves
-	constexpr int D = 4;   // register sets of staged chunks: a step's loads are issued D steps before they are stored to LDS (L2 latency >> one step)
-	uint4 pre[D][3];
-	int stCl[3], stLds[3];
-	const uint4* stPtr[3];
-	bool stOn[3], stExt[3];
+	// ---- row tiles of this block's row range, 64 rows per wave and turn ----
+	// A fragments: tile t, row rowT + 32 t + r; MFMA s (k = 16 s + 8 h ..) reads chunk 2 s + h, the fifth reads chunk 8 / zeros.  Raw chunks
+	// of the NEXT row tile are requested before the current one is swept (their latency is of the order of a whole sweep).
+	uint4 araw[2][5];
+	auto loadA = [&](int rowT) {
 #pragma unroll
-	for (int q = 0; q < 3; q++) {
-		const int g = tid + 256 * q;
-		const int cl = g / ROW_CHUNKS, ch = g - cl * ROW_CHUNKS;
-		stOn[q] = g < 64 * ROW_CHUNKS;
-		stCl[q] = cl;
-		stExt[q] = ch == 8;
-		stLds[q] = (cl >> 5) * (10 * 33) + ch * 33 + (cl & 31);
-		stPtr[q] = A.Hd + (long long)(P.dstOff + B.col0 + cl) * ROW_CHUNKS + ch;
-	}
-	auto fetch = [&](uint4 (&pr)[3], int c0) {
+		for (int t = 0; t < 2; t++) {
+			const int row = rowT + 32 * t + r;
+			if (row < B.row1) {
+				const uint4* src = A.Hs + (long long)(P.srcOff + row) * ROW_CHUNKS;
 #pragma unroll
-		for (int q = 0; q < 3; q++) {
-			if (stOn[q]) {
-				uint4 v;
-				if (c0 + stCl[q] < B.col1) {
-					v = stPtr[q][(long long)(c0 - B.col0) * ROW_CHUNKS];
-					if (stExt[q]) { const unsigned int x = v.x; v.x = v.y; v.y = x; }   // [hi lo | 1 1 | 1 ..] -> [1 1 | hi lo | 1 ..]
-				} else {
-					v = stExt[q] ? extChunk(1.0f, 1.0f, BIG16, 0.0f) : make_uint4(0, 0, 0, 0);
-				}
-				pr[q] = v;
+				for (int s = 0; s < 4; s++) araw[t][s] = src[2 * s + h];
+				araw[t][4] = h == 0 ? src[8] : make_uint4(0, 0, 0, 0);
+			} else {
+#pragma unroll
+				for (int s = 0; s < 4; s++) araw[t][s] = make_uint4(0, 0, 0, 0);
+				araw[t][4] = h == 0 ? extChunk(BIG16, 0.0f, 1.0f, 1.0f) : make_uint4(0, 0, 0, 0);
 			}
 		}
 	};
-	auto stash = [&](int buf, const uint4 (&pr)[3]) {
+	if (B.row0 + 64 * wave < B.row1) loadA(B.row0 + 64 * wave);
+	for (int rowT = B.row0 + 64 * wave; rowT < B.row1; rowT += 256) {
+		h16x8 a[2][5];
 #pragma unroll
-		for (int q = 0; q < 3; q++)
-			if (stOn[q]) (&tileB[buf][0][0])[stLds[q]] = pr[q];
-	};
+		for (int t = 0; t < 2; t++) {
 #pragma unroll
-	for (int k = 0; k < D; k++) fetch(pre[k], B.col0 + 64 * k);
-	stash(0, pre[0]);
-	fetch(pre[0], B.col0 + 64 * D);
-	__syncthreads();
-	for (int cb = B.col0; cb < B.col1; cb += 64 * D) {
+			for (int s = 0; s < 4; s++) a[t][s] = asHalf8(araw[t][s]) * (_Float16)(-2.0f);
+			a[t][4] = asHalf8(araw[t][4]);
+		}
+		if (rowT + 256 < B.row1 && !BHIP_ABLATE(A, 4)) loadA(rowT + 256);
+		// per accumulator register: C layout row = (reg&3) + 8*(reg>>2) + 4h of the tile, col = lane&31
+		unsigned int rowM[32];        // PASS 1: running row minimum of accumulator register (t, g) = [16 t + g] (bit pattern of a positive float)
 #pragma unroll
-		for (int k = 0; k < D; k++) {   // step k of this round reads LDS buffer k & 1 (D is even) and register set (k + 1) % D feeds the next step
-			const int c0 = cb + 64 * k;
-			if (c0 >= B.col1) break;   // block-uniform
-			const int buf = k & 1;
-			const int colA = c0 + r, colB = c0 + 32 + r;
-			const bool okA = colA < B.col1, okB = colB < B.col1;
-			const bool more = c0 + 64 < B.col1;   // block-uniform
+		for (int k = 0; k < 32; k++) rowM[k] = 0xFFFFFFFFu;
+		if (PASS == 2) {
+			waveSyncLds();   // the previous tile's reads of rowThrLds are over
+			rowThrLds[wave][lane] = rowT + lane < B.row1 ? A.rowThr[P.rowBase + rowT + lane] : -INFINITY;
+			waveSyncLds();
+		}
+		for (int ct = 0; ct < ntile; ct += 2) {
+			const bool two = ct + 1 < ntile;   // wave-uniform: an odd tile count leaves the last step with one column tile
+			const int cA_ = 32 * ct + r, cB_ = cA_ + 32;
 			f32x16 acc[2][2];
-			if (live) {
 #pragma unroll
-				for (int t = 0; t < 2; t++)
+			for (int t = 0; t < 2; t++)
 #pragma unroll
-					for (int c = 0; c < 2; c++)
+				for (int c = 0; c < 2; c++)
 #pragma unroll
-						for (int g = 0; g < 16; g++) acc[t][c][g] = 0.0f;
+					for (int g = 0; g < 16; g++) acc[t][c][g] = (c == 0 || two) ? 0.0f : INFINITY;   // a missing second tile never wins a minimum / passes a threshold
 #pragma unroll
-				for (int s = 0; s < 5 && !BHIP_ABLATE(A, 1); s++) {
-					const int ch = s < 4 ? 2 * s + h : 8 + h;
-					const h16x8 b0 = asHalf8(tileB[buf][0][ch * 33 + r]);
-					const h16x8 b1 = asHalf8(tileB[buf][1][ch * 33 + r]);
-					acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b0, acc[0][0], 0, 0, 0);
-					acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b0, acc[1][0], 0, 0, 0);
+			for (int s = 0; s < 5 && !BHIP_ABLATE(A, 1); s++) {
+				const int ch = s < 4 ? 2 * s + h : 8 + h;
+				const h16x8 b0 = asHalf8(tileB[ct][ch * 33 + r]);
+				acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b0, acc[0][0], 0, 0, 0);
+				acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b0, acc[1][0], 0, 0, 0);
+				if (two) {
+					const h16x8 b1 = asHalf8(tileB[ct + 1][ch * 33 + r]);
 					acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b1, acc[0][1], 0, 0, 0);
 					acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b1, acc[1][1], 0, 0, 0);
 				}
 			}
-			if (more && !BHIP_ABLATE(A, 4)) {
-				stash(buf ^ 1, pre[(k + 1) % D]);   // the other buffer was last read before the previous barrier
-				fetch(pre[(k + 1) % D], c0 + 64 * (D + 1));
-			}
-			if (live && !BHIP_ABLATE(A, 2)) {
-				if (PASS == 1) {
-					unsigned int cA = 0xFFFFFFFFu, cB = 0xFFFFFFFFu;
+			if (BHIP_ABLATE(A, 2)) continue;
+			if (PASS == 1) {
+				unsigned int cA = 0xFFFFFFFFu, cB = 0xFFFFFFFFu;
 #pragma unroll
-					for (int t = 0; t < 2; t++)
+				for (int t = 0; t < 2; t++)
 #pragma unroll
-						for (int g = 0; g < 16; g++) {
-							const unsigned int uA = __float_as_uint(acc[t][0][g]), uB = __float_as_uint(acc[t][1][g]);   // positive floats: bit order == value order
-							rowM[t][g] = min(rowM[t][g], min(uA, uB));
-							cA = min(cA, uA);
-							cB = min(cB, uB);
-						}
-					cA = min(cA, (unsigned int)__shfl_xor((int)cA, 32, 64));
-					cB = min(cB, (unsigned int)__shfl_xor((int)cB, 32, 64));
-					if (h == 0) {
-						if (okA) atomicMin(&colLds[colA - B.col0], cA);
-						if (okB) atomicMin(&colLds[colB - B.col0], cB);
+					for (int g = 0; g < 16; g++) {
+						const unsigned int uA = __float_as_uint(acc[t][0][g]), uB = __float_as_uint(acc[t][1][g]);   // positive floats (+inf for a missing tile): bit order == value order
+						rowM[16 * t + g] = min(rowM[16 * t + g], min(uA, uB));
+						cA = min(cA, uA);
+						cB = min(cB, uB);
 					}
-				} else {
-					const float tA = okA ? __uint_as_float(colLds[colA - B.col0]) : -INFINITY;
-					const float tB = okB ? __uint_as_float(colLds[colB - B.col0]) : -INFINITY;
+				cA = min(cA, (unsigned int)__shfl_xor((int)cA, 32, 64));
+				cB = min(cB, (unsigned int)__shfl_xor((int)cB, 32, 64));
+				if (h == 0) {
+					atomicMin(&colLds[cA_], cA);
+					if (two) atomicMin(&colLds[cB_], cB);
+				}
+			} else {
+				const float tA = __uint_as_float(colLds[cA_]);
+				const float tB = two ? __uint_as_float(colLds[cB_]) : -INFINITY;
+				const int colA = B.col0 + cA_, colB = B.col0 + cB_;
 #pragma unroll
-					for (int t = 0; t < 2; t++)
+				for (int t = 0; t < 2; t++)
 #pragma unroll
-						for (int j = 0; j < 4; j++) {
-							// rows 8 j + 4 h + 0..3 of tile t = accumulator registers 4 j .. 4 j + 3: one 16-byte LDS read (same address across a half-wave)
-							const float4 rv = *(const float4*)&rowThrLds[64 * wave + 32 * t + 8 * j + 4 * h];
-							const float rthr[4] = {rv.x, rv.y, rv.z, rv.w};
+					for (int j = 0; j < 4; j++) {
+						// rows 8 j + 4 h + 0..3 of tile t = accumulator registers 4 j .. 4 j + 3: one 16-byte LDS read (same address across a half-wave)
+						const float4 rv = *(const float4*)&rowThrLds[wave][32 * t + 8 * j + 4 * h];
+						const float rthr[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-							for (int q = 0; q < 4; q++) {
-								const int g = 4 * j + q;
-								const float dA = acc[t][0][g], dB = acc[t][1][g];
-								const bool rA = dA <= rthr[q], rB = dB <= rthr[q], qA = dA <= tA, qB = dB <= tB;
-								if (__ballot(rA || rB || qA || qB) != 0ull) {   // wave-uniform, a few times per step
-									const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-									candAdd(A.cand, A.counter, A.cap, candBuf, candN, ((rA || qA) ? 1 : 0) | ((rB || qB) ? 2 : 0), B.p, rr, colA, colB);
-								}
+						for (int q = 0; q < 4; q++) {
+							const int g = 4 * j + q;
+							const float dA = acc[t][0][g], dB = acc[t][1][g];
+							const bool rA = dA <= rthr[q], rB = dB <= rthr[q], qA = dA <= tA, qB = dB <= tB;
+							if (__ballot(rA || rB || qA || qB) != 0ull) {   // wave-uniform, a few times per step
+								const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+								candAdd(A.cand, A.counter, A.cap, candBuf, candN, ((rA || qA) ? 1 : 0) | ((rB || qB) ? 2 : 0), B.p, rr, colA, colB);
 							}
 						}
-				}
+					}
 			}
-			if (!BHIP_ABLATE(A, 8)) __syncthreads();
+		}
+		if (PASS == 1) {
+#pragma unroll
+			for (int k = 0; k < 32; k++) {
+				// minimum over the 32 lanes of the half-wave: four DPP exchanges inside a row of 16 lanes (quad swaps, half-row and row mirror:
+				// plain VALU operands, no LDS round trip) and one cross-row exchange
+				unsigned int v = rowM[k];
+				if (!BHIP_ABLATE(A, 64)) {
+					v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+					v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+					v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+					v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+					v = min(v, (unsigned int)__shfl_xor((int)v, 16, 64));
+				}
+				const int rr = rowT + 32 * (k >> 4) + (k & 3) + 8 * ((k & 15) >> 2) + 4 * h;
+				if (r == 0 && rr < B.row1 && !BHIP_ABLATE(A, 16)) atomicMin(&A.rowKey[P.rowBase + rr], v);
+			}
+		} else {
+			waveSyncLds();
+			if (*candN > CAND_LDS / 2) { candFlush(A, candBuf, candN, B.p, lane); waveSyncLds(); if (lane == 0) *candN = 0; waveSyncLds(); }
 		}
 	}
+	if (PASS == 2) candFlush(A, candBuf, candN, B.p, lane);
 	if (PASS == 1) {
-		// column minima of this block's rows -> global (one atomic per column per block); the last loop barrier ordered the LDS atomics
-		for (int c = tid; c < B.col1 - B.col0; c += 256) atomicMin(&A.colKey[P.colBase + B.col0 + c], colLds[c]);
-	}
-	if (!live) return;
-	if (PASS == 2) {
-		candFlush(A, candBuf, candN, B.p, lane);
-	}
-	if (PASS == 1) {
-#pragma unroll
-		for (int t = 0; t < 2; t++)
-#pragma unroll
-			for (int g = 0; g < 16; g++) {
-				unsigned int v = rowM[t][g];
-#pragma unroll
-				for (int o = 16; o >= 1; o >>= 1) v = min(v, (unsigned int)__shfl_xor((int)v, o, 64));
-				const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-				if (r == 0 && rr < P.ns) atomicMin(&A.rowKey[P.rowBase + rr], v);
-			}
+		__syncthreads();   // every wave's LDS minima are in
+		for (int c = tid; c < ncol && !BHIP_ABLATE(A, 32); c += 256) atomicMin(&A.colKey[P.colBase + B.col0 + c], colLds[c]);
 	}
 }
 
@@ -474,17 +468,17 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 		flopsPerPass += 2.0 * ns[p] * (double)nd[p] * 64;
 		if (rowTotal > 0x3fffffffLL || colTotal > 0x3fffffffLL) return BHIP_OK;
 	}
-	// block table: BLOCK_ROWS rows per block; split the columns when there are too few row blocks to fill the chip
-	long long rowBlocks = 0;
-	for (int p = 0; p < count; p++) rowBlocks += (ns[p] + BLOCK_ROWS - 1) / BLOCK_ROWS;
-	int colSplit = (int)std::max<long long>(1, (1024 + rowBlocks - 1) / rowBlocks);
-	{ const char* e = getenv("BHIP_ASSOC_COLSPLIT"); if (e && atoi(e) > 0) colSplit = atoi(e); }   // tests: force long column sweeps per block
+	// block table: one block per (problem, column strip of <= STRIP_COLS columns, row chunk); the rows are split only when there are too few
+	// strips to fill the chip (a block then accumulates column minima over its chunk and the chunks meet in the global atomics)
+	long long strips = 0;
+	for (int p = 0; p < count; p++) strips += (nd[p] + STRIP_COLS - 1) / STRIP_COLS;
+	int rowSplit = (int)std::max<long long>(1, (1024 + strips - 1) / strips);
+	{ const char* e = getenv("BHIP_ASSOC_ROWSPLIT"); if (e && atoi(e) > 0) rowSplit = atoi(e); }   // tests: force row chunks / whole-problem sweeps
 	for (int p = 0; p < count; p++) {
-		int split = std::min(colSplit, (nd[p] + 63) / 64);
-		int per = (nd[p] + split - 1) / split;
-		per = std::min(COL_CAP, ((per + 63) / 64) * 64);
-		for (int r0 = 0; r0 < ns[p]; r0 += BLOCK_ROWS)
-			for (int c0 = 0; c0 < nd[p]; c0 += per) blocks.push_back({p, r0, c0, std::min(nd[p], c0 + per)});
+		int chunk = (ns[p] + rowSplit - 1) / rowSplit;
+		chunk = std::max(256, ((chunk + 255) / 256) * 256);   // whole turns of the four waves
+		for (int c0 = 0; c0 < nd[p]; c0 += STRIP_COLS)
+			for (int r0 = 0; r0 < ns[p]; r0 += chunk) blocks.push_back({p, r0, std::min(ns[p], r0 + chunk), c0, std::min(nd[p], c0 + STRIP_COLS)});
 	}
 	if (count >= 16) {
 		// Workgroup ids go round-robin over the 8 XCDs: give all blocks of a problem the same id residue so that its destination rows are
@@ -493,7 +487,7 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 		for (const AssocBlock& b : blocks) q[b.p & 7].push_back(b);
 		size_t longest = 0;
 		for (int x = 0; x < 8; x++) longest = std::max(longest, q[x].size());
-		blocks.assign(longest * 8, AssocBlock{0, 0, 0, 0});
+		blocks.assign(longest * 8, AssocBlock{0, 0, 0, 0, 0});
 		for (int x = 0; x < 8; x++)
 			for (size_t k = 0; k < q[x].size(); k++) blocks[k * 8 + x] = q[x][k];
 	}

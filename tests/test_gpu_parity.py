@@ -686,8 +686,9 @@ def test_mfma_association_config3_and_tie_stress(api, orc):
 
 
 def test_mfma_association_long_sweeps(api, orc, tmp_path):
-    """One block sweeping many 64-column steps (the double-buffered LDS tiles of the fp32 MFMA kernel): a single problem normally has its
-    columns split over many blocks, so the split is forced to 1 in a child process (BHIP_ASSOC_COLSPLIT) and compared with the oracle."""
+    """The matrix-core filter keeps one column strip of a problem in LDS and walks the rows in wave tiles; a single problem normally has
+    its rows split into chunks (to fill the chip), a batch does not.  Both plans are forced in child processes (BHIP_ASSOC_ROWSPLIT = 1:
+    every block walks all rows of its strip; = 5: row chunks that meet in the global atomics) and compared with the oracle."""
     import os, subprocess, sys
     rng = np.random.default_rng(3)
     src = _surf_like(rng, 1500); dst = _surf_like(rng, 1300)
@@ -697,12 +698,13 @@ def test_mfma_association_long_sweeps(api, orc, tmp_path):
             "a = api.FactoryAssociation.greedy(api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True); "
             "a.setSource(np.load(%r)); a.setDestination(np.load(%r)); a.associate(); np.save(%r, a.getPairs()); np.save(%r, a.getFitQuality())")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = dict(os.environ); e["BHIP_ASSOC_COLSPLIT"] = "1"
-    subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "s.npy"), str(tmp_path / "d.npy"), str(tmp_path / "p.npy"), str(tmp_path / "f.npy"))],
-                   check=True, env=e, timeout=300)
     ep, ef = orc.associate_l2(src, dst, orc.MAX_VALUE_F64, True, threads=8)
-    assert np.array_equal(np.load(tmp_path / "p.npy"), ep) and np.array_equal(np.load(tmp_path / "f.npy"), ef)
     assert (ep >= 0).sum() > 700
+    for split in ("1", "5"):
+        e = dict(os.environ); e["BHIP_ASSOC_ROWSPLIT"] = split
+        subprocess.run([sys.executable, "-c", code % (root, str(tmp_path / "s.npy"), str(tmp_path / "d.npy"), str(tmp_path / "p.npy"), str(tmp_path / "f.npy"))],
+                       check=True, env=e, timeout=300)
+        assert np.array_equal(np.load(tmp_path / "p.npy"), ep) and np.array_equal(np.load(tmp_path / "f.npy"), ef), split
 
 
 def test_mfma_association_degenerate_inputs_fall_back(api, orc):
