@@ -25,10 +25,12 @@
 //   backward: (i -> m) survives iff i is the only row attaining the exact minimum of column m
 // Degenerate inputs (candidate list overflow, e.g. many near-equal descriptors; non-finite values) fall back to the exact VALU kernels.
 //
-// Layout: one 144-byte row per descriptor = 9 chunks of 8 halves (64 values + [hi lo 1 1 0 0 0 0]).  A wave owns 64 source rows (two A
-// tiles, operands in VGPRs for the whole sweep) and sweeps destination columns 64 at a time (two B tiles staged once per block in LDS,
-// double buffered): 20 MFMAs per step, every B fragment read from LDS feeds two of them.  The norms ride in the contraction, so the
-// epilogue is one v_min3 per two scores (pass 1) or one compare per score (pass 2).
+// Layout: one 144-byte row per descriptor = 9 chunks of 8 halves (64 values + [hi lo 1 1 1 0 0 0]).  A workgroup keeps ONE column strip of
+// a problem (<= 384 destination rows, fragment order) in LDS and walks its row range in wave tiles of 64 rows (two A tiles in VGPRs, the
+// next tile's chunks requested one tile ahead): 20 MFMAs per 64-column step, every B fragment read from LDS feeds two of them, no barrier
+// and no global traffic inside the sweep.  The norms ride in the contraction, so the epilogue is one v_min3_u32 per two scores (pass 1) or
+// one compare per score (pass 2).  Column minima of the strip accumulate in LDS over all row tiles; row minima of a tile are reduced with
+// DPP exchanges and meet the other strips in a global atomicMin.
 // Bound: MFMA (fp16 matrix rate); algorithmic flops per pass = 2 * Ns * Nd * 64.
 #include "common.h"
 #include <cfloat>
