@@ -164,20 +164,19 @@ struct MfmaArgs {
 // listed pair is a real pair, and every pair that can attain a row / column minimum is listed).  Hits are rare per lane, so a hit lane
 // appends with one LDS atomic; the wave flushes its staging area once, with ONE atomicAdd on the global counter (a single contended word
 // sustains only ~88 atomics/us, MI355X_MICROARCH.md).  Entries that do not fit the staging area go to the global list directly.
-// (kept out of line: inlined at the 32 accumulator registers of the hot loop it costs the kernel its register budget)
-__device__ __noinline__ void candAdd(AssocCand* cand, int* counter, int cap, int2* buf, int* cnt, int bits, int p, int rr, int colA, int colB) {
-#pragma unroll 1
-	for (int k = 0; k < 2; k++) {
-		if ((bits >> k) & 1) {
-			const int col = k ? colB : colA;
-			const int pos = atomicAdd(cnt, 1);
-			if (pos < CAND_LDS) {
-				buf[pos] = make_int2(rr, col);
-			} else {
-				const int g = atomicAdd(counter, 1);
-				if (g < cap) { AssocCand c; c.p = p; c.i = rr; c.j = col; c.pad = 0; c.score = 0; cand[g] = c; }
-			}
-		}
+// The staging area is full (a wave tile with several times the usual number of hits): straight to the global list.  Out of line: never on
+// the hot path, and its 64-bit addressing must not cost the sweep registers.
+__device__ __noinline__ void candSlow(AssocCand* cand, int* counter, int cap, int p, int rr, int col) {
+	const int g = atomicAdd(counter, 1);
+	if (g < cap) { AssocCand c; c.p = p; c.i = rr; c.j = col; c.pad = 0; c.score = 0; cand[g] = c; }
+}
+// one hit lane = one LDS atomic + one 8-byte LDS store.  Inlined at every accumulator register so that the pointers stay LDS pointers
+// (ds_add_rtn / ds_write; as an out-of-line function it went through flat atomics and a full wait at entry: 0.08 ms of pass 2)
+__device__ __forceinline__ void candAdd(const MfmaArgs& A, int2* buf, int* cnt, bool hit, int p, int rr, int col) {
+	if (hit) {
+		const int pos = atomicAdd(cnt, 1);
+		if (pos < CAND_LDS) buf[pos] = make_int2(rr, col);
+		else candSlow(A.cand, A.counter, A.cap, p, rr, col);
 	}
 }
 __device__ __forceinline__ void candFlush(const MfmaArgs& A, const int2* buf, const int* cnt, int p, int lane) {
@@ -351,7 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_assoc_mfma(MfmaArgs A) {
 							const bool rA = dA <= rthr[q], rB = dB <= rthr[q], qA = dA <= tA, qB = dB <= tB;
 							if (__ballot(rA || rB || qA || qB) != 0ull) {   // wave-uniform, a few times per step
 								const int rr = rowT + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-								candAdd(A.cand, A.counter, A.cap, candBuf, candN, ((rA || qA) ? 1 : 0) | ((rB || qB) ? 2 : 0), B.p, rr, colA, colB);
+								candAdd(A, candBuf, candN, rA || qA, B.p, rr, colA);
+								candAdd(A, candBuf, candN, rB || qB, B.p, rr, colB);
 							}
 						}
 					}
