@@ -108,7 +108,9 @@ def launch_ranks(args, argv):
         if err:
             sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in err.splitlines()))
         if r == 0:
-            sys.stdout.write(out)
+            # the contract is ONE JSON line on stdout: anything else a library printed there (gloo's connection banner in rehearsal mode) goes to stderr
+            for line in out.splitlines():
+                (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
         elif out:
             sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in out.splitlines()))
         if p.returncode != 0:
@@ -338,14 +340,23 @@ class Dist:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
+        # Rehearsal on a box with fewer GPUs than ranks (BHIP_BENCH_REHEARSAL=1, never a quoted number): the ranks share the visible
+        # devices and the control collectives (barrier, scalar all-reduce) go over gloo -- RCCL cannot put two ranks on one device.
+        self.rehearsal = os.environ.get("BHIP_BENCH_REHEARSAL") == "1"
+        dev_index = self.local_rank % max(torch.cuda.device_count(), 1) if self.rehearsal else self.local_rank
+        self.ctl_device = torch.device("cpu") if self.rehearsal else torch.device("cuda", dev_index)
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local_rank))
+            if self.rehearsal:
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", dev_index))
             self.dist = dist
-        torch.cuda.set_device(self.local_rank)
-        self.device = torch.device("cuda", self.local_rank)
+        torch.cuda.set_device(dev_index)
+        self.local_rank = dev_index
+        self.device = torch.device("cuda", dev_index)
 
     def barrier(self):
         if self.dist is not None:
@@ -355,14 +366,14 @@ class Dist:
     def max(self, x):
         if self.dist is None:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.ctl_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum(self, x):
         if self.dist is None:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.ctl_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
@@ -712,6 +723,8 @@ def main():
     line = {"frames": run_frames, "assoc_sharded": run_assoc_sharded, "chain4k": run_chain4k}[args.workload](args, D)
     if D.rank == 0:
         assert line["n_gpus"] == args.gpus
+        if D.rehearsal:
+            line["rehearsal"] = "ranks share the visible GPU(s), control collectives over gloo: exercises the rank plumbing, NOT a multi-GPU measurement"
         print(json.dumps(line), flush=True)
     D.close()
 
