@@ -87,6 +87,8 @@ __device__ __forceinline__ GradGeom makeGeom(int r, int stride, int W, int H) {
 // gradFetch issues the taps with NO control flow (a sample that is switched off, or whose kernel leaves the image, reads the safe position
 // instead; an image smaller than the kernel collapses every offset to 0), gradFinish combines them in the reference's order.
 template <class T>
+struct __attribute__((packed, aligned(4))) Pair2 { T x, y; };   // two neighbouring taps, any 4-byte alignment
+template <class T>
 struct GradTaps {
 	T p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11;
 	bool inb;
@@ -105,10 +107,20 @@ __device__ __forceinline__ void gradFetch(const T* __restrict__ d, const GradGeo
 	const unsigned int s2 = s1 + rr * st;
 	const unsigned int s3 = s2 + st;
 	const unsigned int s4 = s3 + rr * st;
-	t.p0 = d[s1]; t.p1 = d[s1 + rr]; t.p2 = d[s1 + rr + one]; t.p3 = d[s1 + w];
+	t.p0 = d[s1]; t.p3 = d[s1 + w];
 	t.p11 = d[s2]; t.p4 = d[s2 + w];
 	t.p10 = d[s3]; t.p5 = d[s3 + w];
-	t.p9 = d[s4]; t.p8 = d[s4 + rr]; t.p7 = d[s4 + rr + one]; t.p6 = d[s4 + w];
+	t.p9 = d[s4]; t.p6 = d[s4 + w];
+	if (G.anyInside) {
+		// the two centre columns of the top and of the bottom row are neighbours: one 8-byte request each instead of two 4-byte ones
+		// (the texture addresser is this kernel's co-limiter and works per lane access, not per byte)
+		const Pair2<T> a = *(const Pair2<T>*)(d + s1 + rr), b = *(const Pair2<T>*)(d + s4 + rr);
+		t.p1 = a.x; t.p2 = a.y;
+		t.p8 = b.x; t.p7 = b.y;
+	} else {
+		t.p1 = d[s1 + rr]; t.p2 = d[s1 + rr + one];
+		t.p8 = d[s4 + rr]; t.p7 = d[s4 + rr + one];
+	}
 	t.inb = inb;
 }
 template <class T>
