@@ -54,6 +54,42 @@ public class DetectDescribeSurfHip implements DetectDescribePoint<GrayF32, Brigh
 	@Override public boolean hasScale() { return true; }
 	@Override public boolean hasOrientation() { return true; }
 
+	// ---- batch-level calls (no counterpart in the reference interface; what a provider uses when it processes a list of frames) ----
+	private int batch;
+	private int[] starts = new int[1];
+
+	/** Detect + describe a list of frames of one shape in ONE native call (bhip_surf_detect_f32 with batch > 1: host batches of 64 frames
+	 *  or more are uploaded in chunks while the previous chunk is processed).  The per-image getters then refer to image 0; use
+	 *  fetchAll / associateImages for the whole batch. */
+	public void detectBatch(java.util.List<GrayF32> frames) {
+		if (frames.isEmpty()) throw new IllegalArgumentException("empty batch");
+		final int w = frames.get(0).width, h = frames.get(0).height;
+		float[][] data = new float[frames.size()][];
+		int[] start = new int[frames.size()], stride = new int[frames.size()];
+		for (int i = 0; i < frames.size(); i++) {
+			GrayF32 f = frames.get(i);
+			if (f.width != w || f.height != h) throw new IllegalArgumentException("all images of a batch must have the same shape");
+			data[i] = f.data; start[i] = f.startIndex; stride[i] = f.stride;
+		}
+		BoofHip.check(ctx, BoofHip.surfDetectF32(surf, data, start, stride, w, h, frames.size()));
+		batch = frames.size();
+		starts = new int[batch + 1];
+		for (int i = 0; i < batch; i++) { BoofHip.check(ctx, BoofHip.surfCount(surf, i, tmp)); starts[i + 1] = starts[i] + tmp[0]; }
+	}
+
+	/** Every location / orientation / sign / descriptor of the last batch in one set of copies (bhip_surf_fetch_all); image i owns rows
+	 *  starts()[i] .. starts()[i+1] of the returned arrays (xy_scale has 3 values per row, desc 64). */
+	public void fetchAll(double[] xyScale, double[] angles, byte[] whites, double[] descs) {
+		if (starts[batch] > 0) BoofHip.check(ctx, BoofHip.surfFetchAll(surf, xyScale, angles, whites, descs));
+	}
+	public int[] starts() { return starts; }
+
+	/** Greedy Euclidean-squared association of image srcImage[p] with image dstImage[p] of the last batch on the descriptors that are still
+	 *  resident on the device (bhip_assoc_l2_surf; AssociateGreedy.java:65-118 rules).  pairs / fit are indexed like fetchAll's rows. */
+	public void associateImages(int[] srcImage, int[] dstImage, double maxError, boolean backwardsValidation, int[] pairs, double[] fit) {
+		BoofHip.check(ctx, BoofHip.assocL2Surf(surf, srcImage.length, srcImage, dstImage, maxError, backwardsValidation ? 1 : 0, pairs, fit));
+	}
+
 	/** the native object is released with the owner (Java has no deterministic destructor: call when done) */
 	public void close() { BoofHip.surfDestroy(surf); }
 }
