@@ -493,15 +493,17 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	// re-reads of neighbouring tiles hit that XCD's 4 MB L2 instead of going out to the fabric.  Speed only, never correctness.
 	int bx, by, img;
 	{
-		const int tilesX = (P.w + G::TX - 1) / G::TX, tilesY = (P.h + G::TY - 1) / G::TY;
-		const long long ntiles = (long long)tilesX * tilesY * P.batch;
-		const long long chunk = (ntiles + 7) >> 3;
-		const long long lin = (long long)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+		// (32-bit arithmetic: the launcher refuses more than 2^31 tiles; a 64-bit division here costs ~250 scalar instructions per wave)
+		const unsigned int tilesX = (unsigned)((P.w + G::TX - 1) / G::TX), tilesY = (unsigned)((P.h + G::TY - 1) / G::TY);
+		const unsigned int perImage = tilesX * tilesY;
+		const unsigned int ntiles = perImage * (unsigned)P.batch;
+		const unsigned int chunk = (ntiles + 7u) >> 3;
+		const unsigned int lin = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
 		if ((blockIdx.x >> 3) >= chunk || lin >= ntiles) return;
-		img = (int)(lin / ((long long)tilesX * tilesY));
-		const int rem = (int)(lin - (long long)img * tilesX * tilesY);
-		by = rem / tilesX;
-		bx = rem - by * tilesX;
+		img = (int)(lin / perImage);
+		const unsigned int rem = lin - (unsigned)img * perImage;
+		by = (int)(rem / tilesX);
+		bx = (int)(rem - (unsigned)by * tilesX);
 	}
 	const int x0 = bx * G::TX, y0 = by * G::TY;
 	const T* __restrict__ d = (const T*)P.ii.data + (long long)img * P.ii.imageStride;
@@ -833,6 +835,7 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 	do {                                                                                                                               \
 		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV> G;                                                                               \
 		const long long nt = (long long)((P.w + G::TX - 1) / G::TX) * ((P.h + G::TY - 1) / G::TY) * batch;                              \
+		if (nt > 0x7ffffff0LL) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "batch too large for one fused-octave launch");             \
 		dim3 g((unsigned)(((nt + 7) >> 3) << 3));                                                                                      \
 		if (intTaps) hipLaunchKernelGGL((k_detect_fused_fixed<int, SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
 		else hipLaunchKernelGGL((k_detect_fused_fixed<float, SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
