@@ -1386,13 +1386,10 @@ int bhip_pyramid_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, const int* 
 		const int lw = dims[2 * i], lh = dims[2 * i + 1];
 		if (i == 0 && scales[0] == 1) {
 			ProfScope prof(ctx, "pyramid_copy", 8.0 * width * height * batch);
-			for (int b = 0; b < batch; b++)
-				BHIP_HIP(ctx, hipMemcpy2DAsync(layer + (long long)b * total, (size_t)lw * 4, dev_in + (long long)b * inImageStride, (size_t)inStride * 4,
-											   (size_t)width * 4, (size_t)height, hipMemcpyDeviceToDevice, ctx->stream));
+			BHIP_TRY(bhip_launch_copy_images(ctx, dev_in, inImageStride, inStride, layer, total, lw, width, height, batch));
 		} else {
 			const int skip = i == 0 ? scales[0] : scales[i] / scales[i - 1];
-			const int tw = pw / skip;
-			if (tw <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "pyramid layer collapses to zero width");
+			const int tw = pw / skip;   // 0 when the layer below is narrower than the step: both passes then write nothing and the (ceil-sized) layer stays zero, as in the reference
 			BHIP_TRY(bhip_launch_conv_down(ctx, false, kernel, kw, prev, prevImageStride, prevStride, pw, ph, sc->d.as<float>(), tempCap, tw, tw, ph, skip,
 										   batch));
 			BHIP_TRY(bhip_launch_conv_down(ctx, true, kernel, kw, sc->d.as<float>(), tempCap, tw, tw, ph, layer, total, lw, lw, lh, skip, batch));

@@ -171,6 +171,9 @@ int bhip_launch_hessian(bhip_ctx* ctx, ImgView ii, int batch, int skip, int nlev
 						long long imageStrideOut, int outStride, const HessLevelSource* from = nullptr, bool intTaps = false,
 						unsigned int skipMask = 0);   // skipMask: levels this launch does not produce
 
+int bhip_launch_copy_images(bhip_ctx* ctx, const float* in, long long inImageStride, int inStride, float* out, long long outImageStride, int outStride,
+							int width, int height, int batch);
+
 // describe-kernel options beyond the grey float default (see DescParams): colour SURF bands (nBands > 0), the orientation's object
 // radius factor, integer taps (GrayS32 integral images)
 struct DescPlanar {

@@ -512,14 +512,29 @@ struct ConvDownParams {
 	int skip, kw, radius;
 	int unrolled, naive;
 	int offset, offsetRem, maxSide, offsetEnd, sideTrunc;   // along the filtered axis
+	int skipInterior;   // general kernel only: the interior outputs have been written by a streaming kernel
 	float k[BHIP_MAX_TAPS];
 };
 
 template <bool VERTICAL>
 __global__ __launch_bounds__(256) void k_conv_down(ConvDownParams P) {
-	const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-	const int oy = blockIdx.y;
+	int ox = blockIdx.x * blockDim.x + threadIdx.x;
+	int oy = blockIdx.y;
 	const int outW = VERTICAL ? P.width : P.width / P.skip;
+	if (P.skipInterior) {
+		// border fix-up after a streaming kernel: the grid covers only the outputs whose centre lies left of `offset` or at / beyond
+		// `offsetEnd` (horizontal: flat grid, consecutive threads take the border columns of one row, then the next row)
+		const int outSide = (VERTICAL ? P.height : P.width) / P.skip;
+		const int nl = min((P.offset + P.skip - 1) / P.skip, outSide), dR0 = max(nl, min((P.offsetEnd + P.skip - 1) / P.skip, outSide));
+		const int nb = nl + (outSide - dR0);
+		if (nb <= 0) return;
+		int t;
+		if (VERTICAL) { t = oy; }
+		else { oy = ox / nb; t = ox - oy * nb; if (oy >= P.height) return; }
+		if (t >= nb) return;
+		const int D = t < nl ? t : dR0 + (t - nl);
+		if (VERTICAL) oy = D; else ox = D;
+	}
 	if (ox >= outW) return;
 	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
 	const int D = VERTICAL ? oy : ox;
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(256) void k_conv_down(ConvDownParams P) {
 		k1 = r;
 	} else {
 		centre += P.offsetRem;
-		if (centre > P.maxSide) return;
+		if (centre > P.maxSide || P.skipInterior) return;
 		k0 = -r; k1 = r;
 		normalise = false;
 	}
@@ -559,6 +574,114 @@ __global__ __launch_bounds__(256) void k_conv_down(ConvDownParams P) {
 		result = P.unrolled ? tapsUnrolled(s0, step, P.k, P.kw) : tapsStandard(s0, step, P.k, P.kw);
 	}
 	P.out[(long long)blockIdx.z * P.outImageStride + (long long)oy * P.outStride + ox] = result;
+}
+
+// ---- streaming forms for skip 2 and the unrolled widths 3 and 5 (the discrete pyramid's usual layer step) ----
+// Only INTERIOR outputs (the closed form above) are written here; the general kernel adds the border outputs afterwards (skipInterior).
+__device__ __forceinline__ bool downInterior(const ConvDownParams& P, int D) {
+	const int centre = D * P.skip;
+	if (centre >= P.offsetEnd && centre < P.sideTrunc) return false;   // right border
+	if (centre < P.offset) return false;                               // left border
+	return centre + P.offsetRem <= P.maxSide;
+}
+// Horizontal: lane l owns input columns 4l..4l+3 of a 256-column strip = outputs 2l, 2l+1 (centres 4l and 4l+2; the kernel reaches at most
+// two columns into the neighbouring chunks, which arrive by lane shifts); rows as in k_conv_h_stream.
+#define CD_ROWS 8
+template <int KW>
+__global__ __launch_bounds__(256) void k_conv_down_h_stream(ConvDownParams P) {
+	constexpr int R = KW / 2, NB = 4;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;          // first input column of this lane
+	const int y0 = (blockIdx.y * 4 + wave) * CD_ROWS;
+	if (x >= P.width || y0 >= P.height) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride;
+	const int yEnd = min(y0 + CD_ROWS, P.height);
+	const int outW = P.width / 2;
+	const int D0 = x >> 1;                              // outputs D0, D0 + 1
+	const bool w0 = D0 < outW && downInterior(P, D0), w1 = D0 + 1 < outW && downInterior(P, D0 + 1);
+	const bool first = lane == 0, last = lane == 63;
+	float4 own[NB], edge[NB];
+	auto fetch = [&](float4& own, float4& edge, int y) {
+		if (y < yEnd) {
+			const float* row = img + (long long)y * P.inStride;
+			own = loadRow4(row, x, P.width);
+			if (first) edge = loadRow4(row, x - 4, P.width);
+			if (last) edge = loadRow4(row, x + 4, P.width);
+		}
+	};
+	auto emit = [&](const float4& own, const float4& edge, int y) {
+		if (y >= yEnd) return;   // wave-uniform
+		float4 lf, rt;
+		lf.z = __shfl_up(own.z, 1, 64); lf.w = __shfl_up(own.w, 1, 64);
+		rt.x = __shfl_down(own.x, 1, 64);
+		if (first) { lf.z = edge.z; lf.w = edge.w; }
+		if (last) rt.x = edge.x;
+		// v[i] = input column x - 2 + i
+		const float v[7] = {lf.z, lf.w, own.x, own.y, own.z, own.w, rt.x};
+		float r[2];
+#pragma unroll
+		for (int j = 0; j < 2; j++) {
+			// centre x + 2 j = v[2 + 2 j]; taps centre - R .. centre + R, first tap assigns (ConvolveDownNoBorderUnrolled_F32_F32)
+			float total = v[2 + 2 * j - R] * P.k[0];
+#pragma unroll
+			for (int i = 1; i < KW; i++) total += v[2 + 2 * j - R + i] * P.k[i];
+			r[j] = total;
+		}
+		float* dst = outImg + (long long)y * P.outStride + D0;
+		if (w0 && w1) *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
+		else { if (w0) dst[0] = r[0]; if (w1) dst[1] = r[1]; }
+	};
+#pragma unroll
+	for (int q = 0; q < NB; q++) fetch(own[q], edge[q], y0 + q);
+	for (int y = y0; y < yEnd; y += NB) {
+#pragma unroll
+		for (int q = 0; q < NB; q++) {
+			emit(own[q], edge[q], y + q);
+			fetch(own[q], edge[q], y + q + NB);
+		}
+	}
+}
+// Vertical: lane l owns columns 4l..4l+3; a wave produces CD_ROWS_V output rows, walking the 2 CD_ROWS_V + KW - 2 input rows it needs once
+// through a register window of KW rows (two new rows per output).
+#define CD_ROWS_V 8
+template <int KW>
+__global__ __launch_bounds__(256) void k_conv_down_v_stream(ConvDownParams P) {
+	constexpr int R = KW / 2;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;
+	const int outH = P.height / 2;
+	const int o0 = (blockIdx.y * 4 + wave) * CD_ROWS_V;
+	if (x >= P.width || o0 >= outH) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride + x;
+	const int oEnd = min(o0 + CD_ROWS_V, outH);
+	const bool full4 = x + 3 < P.width;
+	auto loadRow = [&](int yy) -> float4 {
+		if (yy < 0 || yy >= P.height) return make_float4(0, 0, 0, 0);   // only ever feeds outputs that are not interior
+		return loadRow4(img + (long long)yy * P.inStride, x, P.width);
+	};
+	// win[i] = input row 2 o - R + i of the current output o
+	float4 win[KW];
+#pragma unroll
+	for (int i = 0; i < KW; i++) win[i] = loadRow(2 * o0 - R + i);
+	for (int o = o0; o < oEnd; o++) {
+		float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+		if (o + 1 < oEnd) { n0 = loadRow(2 * o + R + 1); n1 = loadRow(2 * o + R + 2); }   // the two rows the next output adds
+		if (downInterior(P, o)) {
+			float r[4] = {win[0].x * P.k[0], win[0].y * P.k[0], win[0].z * P.k[0], win[0].w * P.k[0]};
+#pragma unroll
+			for (int i = 1; i < KW; i++) { r[0] += win[i].x * P.k[i]; r[1] += win[i].y * P.k[i]; r[2] += win[i].z * P.k[i]; r[3] += win[i].w * P.k[i]; }
+			float* dst = outImg + (long long)o * P.outStride;
+			if (full4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+			else
+				for (int q = 0; q < 4 && x + q < P.width; q++) dst[q] = r[q];
+		}
+#pragma unroll
+		for (int i = 0; i + 2 < KW; i++) win[i] = win[i + 2];
+		win[KW - 2] = n0;
+		win[KW - 1] = n1;
+	}
 }
 
 static int downMaxSide(int sideLength, int skip, int radius) {
@@ -612,8 +735,58 @@ int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int
 	if (gw <= 0 || gh <= 0 || batch <= 0) return BHIP_OK;
 	ProfScope prof(ctx, vertical ? "k_conv_down_v" : "k_conv_down_h", 4.0 * batch * ((double)width * height + (double)gw * gh));
 	dim3 grid((gw + 255) / 256, gh, batch);
-	if (vertical) hipLaunchKernelGGL(k_conv_down<true>, grid, dim3(256), 0, ctx->stream, P);
+	P.skipInterior = 0;
+	// skip 2, unrolled widths 3 / 5, 16-byte aligned rows: the interior goes through the streaming kernels, the general kernel adds the borders
+	const bool stream = !P.naive && skip == 2 && P.unrolled && (kw == 3 || kw == 5) && P.offsetRem == 0 && aligned16(in) && aligned16(out) &&
+						inStride % 4 == 0 && inImageStride % 4 == 0 && outStride % 4 == 0 && outImageStride % 4 == 0;
+	if (stream) {
+		if (vertical) {
+			dim3 g((width + 255) / 256, (gh + 4 * CD_ROWS_V - 1) / (4 * CD_ROWS_V), batch);
+			if (kw == 3) hipLaunchKernelGGL(k_conv_down_v_stream<3>, g, dim3(256), 0, ctx->stream, P);
+			else hipLaunchKernelGGL(k_conv_down_v_stream<5>, g, dim3(256), 0, ctx->stream, P);
+		} else {
+			dim3 g((width + 255) / 256, (height + 4 * CD_ROWS - 1) / (4 * CD_ROWS), batch);
+			if (kw == 3) hipLaunchKernelGGL(k_conv_down_h_stream<3>, g, dim3(256), 0, ctx->stream, P);
+			else hipLaunchKernelGGL(k_conv_down_h_stream<5>, g, dim3(256), 0, ctx->stream, P);
+		}
+		P.skipInterior = 1;
+	}
+	if (stream) {
+		// the few border outputs of the filtered axis (see k_conv_down, skipInterior)
+		const int outSide = (vertical ? height : width) / skip;
+		const int nl = std::min((P.offset + skip - 1) / skip, outSide), dR0 = std::max(nl, std::min((P.offsetEnd + skip - 1) / skip, outSide));
+		const int nb = nl + (outSide - dR0);
+		if (nb > 0) {
+			if (vertical) hipLaunchKernelGGL(k_conv_down<true>, dim3((gw + 255) / 256, nb, batch), dim3(256), 0, ctx->stream, P);
+			else hipLaunchKernelGGL(k_conv_down<false>, dim3((unsigned)(((long long)height * nb + 255) / 256), 1, batch), dim3(256), 0, ctx->stream, P);
+		}
+	} else if (vertical) hipLaunchKernelGGL(k_conv_down<true>, grid, dim3(256), 0, ctx->stream, P);
 	else hipLaunchKernelGGL(k_conv_down<false>, grid, dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---------------- batched image copy (pyramid layer 0 at scale 1: ImagePyramidBase keeps a copy of the input) ----------------
+__global__ __launch_bounds__(256) void k_copy_images(const float* __restrict__ in, long long inImageStride, int inStride, float* __restrict__ out,
+													   long long outImageStride, int outStride, int width, int height, int vec) {
+	const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+	if (x >= width) return;
+	const float* src = in + (long long)blockIdx.z * inImageStride + x;
+	float* dst = out + (long long)blockIdx.z * outImageStride + x;
+	for (int y = blockIdx.y; y < height; y += gridDim.y) {
+		const float* s = src + (long long)y * inStride;
+		float* d = dst + (long long)y * outStride;
+		if (vec && x + 3 < width) *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(s);
+		else
+			for (int q = 0; q < 4 && x + q < width; q++) d[q] = s[q];
+	}
+}
+int bhip_launch_copy_images(bhip_ctx* ctx, const float* in, long long inImageStride, int inStride, float* out, long long outImageStride, int outStride,
+							int width, int height, int batch) {
+	if (width <= 0 || height <= 0 || batch <= 0) return BHIP_OK;
+	const int vec = aligned16(in) && aligned16(out) && inStride % 4 == 0 && outStride % 4 == 0 && inImageStride % 4 == 0 && outImageStride % 4 == 0;
+	dim3 grid((width + 1023) / 1024, std::min(height, 256), batch);
+	hipLaunchKernelGGL(k_copy_images, grid, dim3(256), 0, ctx->stream, in, inImageStride, inStride, out, outImageStride, outStride, width, height, vec);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;
 }
