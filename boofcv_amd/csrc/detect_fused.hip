@@ -249,8 +249,9 @@ __global__ __launch_bounds__(256) void k_detect_fused(FusedParams P) {
 // Compile-time geometry variant for the reference's default schedule (sizes SIZE0 + i*STEPSZ, NL levels, NMS radius R): every tap
 // offset becomes an immediate of a ds_read, pairs of taps in one row fuse into ds_read2, and the address arithmetic per intensity value
 // shrinks to one base.  Same arithmetic, same decisions as k_detect_fused.
-template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
+template <int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT, int NTT = 256>
 struct FixedGeo {
+	static constexpr int NT = NTT, NW = NTT / 64;   // threads / waves per workgroup
 	static constexpr int TX = ITWT - 2 * R, TY = TYT, ITW = ITWT, ITH = TYT + 2 * R, ITp = ITWT + 1, HALO = R;
 	static constexpr int sizeMax = SIZE0 + (NL - 1) * STEPSZ;
 	static constexpr int rFmax = sizeMax / 2;
@@ -414,7 +415,7 @@ __device__ __forceinline__ void fusedLevelDense(const FusedParams& P, const T* i
 	if (interior) {
 		const int rowBase = (y0 - R) * SKIP - Y0;   // == rFmax + 1
 		if constexpr (SKIP == 1 && T(0.5f) != T(0)) {   // float taps, octave 0: two pixels per thread on packed fp32 (no gain on the staging-bound octave 1)
-			for (int it = tid; it < G::ITH * (G::ITW / 2); it += 256) {
+			for (int it = tid; it < G::ITH * (G::ITW / 2); it += G::NT) {
 				const int px = 2 * (it & (G::ITW / 2 - 1)), py = it / (G::ITW / 2);
 				const f32x2 det = fusedInnerDet2<G, L>((const float*)iiT + (rowBase + py * SKIP) * pitch + px);
 				out[py * G::ITp + px] = det.x;
@@ -422,7 +423,7 @@ __device__ __forceinline__ void fusedLevelDense(const FusedParams& P, const T* i
 			}
 		} else {
 #pragma unroll 2
-			for (int it = tid; it < G::ITH * G::ITW; it += 256) {
+			for (int it = tid; it < G::ITH * G::ITW; it += G::NT) {
 				const int px = it & (G::ITW - 1), py = it / G::ITW;
 				const T* c = iiT + (rowBase + py * SKIP) * pitch + px;
 				out[py * G::ITp + px] = fusedInnerDet<G, L, T>(c);
@@ -430,7 +431,7 @@ __device__ __forceinline__ void fusedLevelDense(const FusedParams& P, const T* i
 		}
 	} else {
 #pragma unroll 1
-		for (int it = tid; it < G::ITH * G::ITW; it += 256) {
+		for (int it = tid; it < G::ITH * G::ITW; it += G::NT) {
 			const int px = it & (G::ITW - 1), py = it / G::ITW;
 			out[py * G::ITp + px] = fusedPixelCall<G, SKIP, L, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x0 - R + px, y0 - R + py, x0, y0, X0, Y0);
 		}
@@ -481,9 +482,9 @@ __device__ __forceinline__ void fusedFinish(const FusedParams& P, const FusedMid
 	}
 }
 
-template <class T, int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT>
-__global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
-	typedef FixedGeo<SKIP, SIZE0, STEPSZ, NL, R, ITWT, TYT> G;
+template <class T, int SKIP, int SIZE0, int STEPSZ, int NL, int R, int ITWT, int TYT, int NTT = 256>
+__global__ __launch_bounds__(NTT) void k_detect_fused_fixed(FusedParams P) {
+	typedef FixedGeo<SKIP, SIZE0, STEPSZ, NL, R, ITWT, TYT, NTT> G;
 	extern __shared__ __attribute__((aligned(16))) float fl[];
 	T* iiT = (T*)fl;   // 32-bit words either way
 	float* inten = fl + SKIP * G::plane;   // the two dense mid levels, then the survivor list and its sparse outer-level values
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	if constexpr (SKIP == 1 || SKIP == 2) {
 		constexpr int SH = SKIP == 1 ? 0 : 2;                  // patch column 0 sits SH elements after the aligned start
 		constexpr int IW4 = (G::IW + SH + 3) / 4;
-		constexpr int ITEMS = G::IH * IW4, NIT = (ITEMS + 255) / 256;
+		constexpr int ITEMS = G::IH * IW4, NIT = (ITEMS + G::NT - 1) / G::NT;
 		const T* src0 = d + (long long)Y0 * stride + (X0 - SH);
 		const bool vecOk = !BHIP_ABLATE(P, 4) && X0 - SH >= 0 && Y0 >= 0 && X0 - SH + 4 * IW4 <= W && Y0 + G::IH <= H && (stride & 3) == 0 &&
 						   (((unsigned long long)src0) & 15ull) == 0;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			int4 v[NIT];
 #pragma unroll
 			for (int it = 0; it < NIT; it++) {
-				const int item = tid + 256 * it;
+				const int item = tid + G::NT * it;
 				if (item < ITEMS) {
 					const int row = item / IW4, c4 = item - row * IW4;
 					v[it] = *(const int4*)(src0 + (long long)row * stride + 4 * c4);
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			}
 #pragma unroll
 			for (int it = 0; it < NIT; it++) {
-				const int item = tid + 256 * it;
+				const int item = tid + G::NT * it;
 				if (item < ITEMS) {
 					const int row = item / IW4, c4 = item - row * IW4;
 					const int e[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
@@ -562,13 +563,13 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			const int tx = tid & 63, ty = tid >> 6;
 			constexpr int PAIRS = G::IW / 2;
 			static_assert(PAIRS <= 64, "one lane per float2 of a patch row");
-			constexpr int RB = (G::IH + 7) / 8;
-			for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
+			constexpr int RB = (G::IH + 2 * G::NW - 1) / (2 * G::NW);
+			for (int ry0 = ty; ry0 < G::IH; ry0 += G::NW * RB) {
 				typedef typename TapVec2<T>::type T2;
 				T2 v[RB];
 #pragma unroll
 				for (int k = 0; k < RB; k++) {
-					const int ry = ry0 + 4 * k;
+					const int ry = ry0 + G::NW * k;
 					const int gy = Y0 + ry;
 					const int gx = X0 + 2 * tx;
 					const bool ok = ry < G::IH && gy >= 0 && gy < H && tx < PAIRS && gx >= 0 && gx < W;
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 				}
 #pragma unroll
 				for (int k = 0; k < RB; k++) {
-					const int ry = ry0 + 4 * k;
+					const int ry = ry0 + G::NW * k;
 					if (ry < G::IH && tx < PAIRS) {
 						iiT[ry * G::IWp + tx] = v[k].x;
 						iiT[G::plane + ry * G::IWp + tx] = v[k].y;
@@ -592,12 +593,12 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		// stage the patch: every thread keeps a batch of independent global loads in flight before the first LDS store
 		const int tx = tid & 63, ty = tid >> 6;
 		constexpr int COLS = (G::IW + 63) / 64;   // 64-float column chunks per row
-		constexpr int RB = (G::IH + 7) / 8;       // rows per batch: the whole patch in two batches of independent loads
-		for (int ry0 = ty; ry0 < G::IH; ry0 += 4 * RB) {
+		constexpr int RB = (G::IH + 2 * G::NW - 1) / (2 * G::NW);   // rows per batch: the whole patch in two batches of independent loads
+		for (int ry0 = ty; ry0 < G::IH; ry0 += G::NW * RB) {
 			T v[RB][COLS];
 #pragma unroll
 			for (int k = 0; k < RB; k++) {
-				const int ry = ry0 + 4 * k;
+				const int ry = ry0 + G::NW * k;
 				const int gy = Y0 + ry;
 				const bool rowOk = ry < G::IH && gy >= 0 && gy < H;
 				const T* __restrict__ src = d + (long long)(rowOk ? gy : 0) * stride;
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 			}
 #pragma unroll
 			for (int k = 0; k < RB; k++) {
-				const int ry = ry0 + 4 * k;
+				const int ry = ry0 + G::NW * k;
 #pragma unroll
 				for (int cc = 0; cc < COLS; cc++) {
 					const int rx = cc * 64 + tx;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 		// evaluated here (a quarter of the core's pixels).
 		constexpr int HX = (G::TX + 1) / 2, HY = (G::TY + 1) / 2;
 		const int ex0 = (x0 + 1) >> 1, ey0 = (y0 + 1) >> 1;   // first even pixel of the core, in next-octave coordinates
-		for (int it = tid; it < P.nexp * HX * HY; it += 256) {
+		for (int it = tid; it < P.nexp * HX * HY; it += G::NT) {
 			const int k = it / (HX * HY);
 			const int rem = it - k * (HX * HY);
 			const int jy = rem / HX, jx = rem - jy * HX;
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	//      threshold lose against one of them); what is left (a few per cent) is compacted into a workgroup-wide list;
 	//   2. one listed pixel per thread: frame tests, the full window, the ignore border -> survivor list.
 	{
-		constexpr int SL = 256 / G::ITW;           // row slices a pass of 256 threads covers (ITW lanes per row)
+		constexpr int SL = G::NT / G::ITW;         // row slices a pass of the workgroup covers (ITW lanes per row)
 		const int px = tid & (G::ITW - 1), slice = tid / G::ITW;
 		for (int row = slice; row < P.nmid * G::TY && !BHIP_ABLATE(P, 2); row += SL) {
 			const int m = row / G::TY, py = row - m * G::TY;
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	__syncthreads();
 	{
 		const int ncand = *candCount;
-		for (int ci = tid; ci < ncand; ci += 256) {
+		for (int ci = tid; ci < ncand; ci += G::NT) {
 			const int cc = candList[ci];
 			const int m = cc >> 12, py = (cc >> 6) & 63, px = cc & 63;
 			const int code = (m << 16) | (py << 8) | px;
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 	for (int base = 0; base < nSurv; base += G::CHUNK) {   // one round for all but the densest tiles
 		const int nHere = min(G::CHUNK, nSurv - base);
 		// ---- outer level around every survivor: nine values each, one (survivor, neighbour) pair per thread
-		for (int it = tid; it < nHere * 9; it += 256) {
+		for (int it = tid; it < nHere * 9; it += G::NT) {
 			const int sv = it / 9, q = it - sv * 9;
 			const int code = survList[base + sv];
 			const int m = code >> 16, py = (code >> 8) & 0xff, px = code & 0xff;
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(256) void k_detect_fused_fixed(FusedParams P) {
 															  : fusedPixelCall<G, SKIP, 3, T>(P.ii.width, P.ii.height, P.w, P.h, iiT, x, y, x0, y0, X0, Y0);
 		}
 		__syncthreads();
-		for (int sv = tid; sv < nHere; sv += 256) {
+		for (int sv = tid; sv < nHere; sv += G::NT) {
 			const int code = survList[base + sv];
 			const int m = code >> 16, py = (code >> 8) & 0xff, px = code & 0xff;
 			const float val = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2)[(py + R) * G::ITp + (px + R)];
@@ -831,24 +832,37 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 #else
 			const char v = 0;
 #endif
-#define LAUNCH_FIXED(SK, S0, ST, ITWV, TYV)                                                                                             \
+#define LAUNCH_FIXED(SK, S0, ST, ITWV, TYV, NTV)                                                                                        \
 	do {                                                                                                                               \
-		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV> G;                                                                               \
+		typedef FixedGeo<SK, S0, ST, 4, 2, ITWV, TYV, NTV> G;                                                                          \
 		const long long nt = (long long)((P.w + G::TX - 1) / G::TX) * ((P.h + G::TY - 1) / G::TY) * batch;                              \
 		if (nt > 0x7ffffff0LL) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "batch too large for one fused-octave launch");             \
 		dim3 g((unsigned)(((nt + 7) >> 3) << 3));                                                                                      \
-		if (intTaps) hipLaunchKernelGGL((k_detect_fused_fixed<int, SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
-		else hipLaunchKernelGGL((k_detect_fused_fixed<float, SK, S0, ST, 4, 2, ITWV, TYV>), g, dim3(256), (size_t)G::ldsFloats * 4, ctx->stream, P); \
+		const size_t ldsB = (size_t)G::ldsFloats * 4;                                                                                  \
+		if (intTaps) {                                                                                                                 \
+			if (ldsB > 65536) BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_detect_fused_fixed<int, SK, S0, ST, 4, 2, ITWV, TYV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB)); \
+			hipLaunchKernelGGL((k_detect_fused_fixed<int, SK, S0, ST, 4, 2, ITWV, TYV, NTV>), g, dim3(NTV), ldsB, ctx->stream, P);      \
+		} else {                                                                                                                       \
+			if (ldsB > 65536) BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_detect_fused_fixed<float, SK, S0, ST, 4, 2, ITWV, TYV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB)); \
+			hipLaunchKernelGGL((k_detect_fused_fixed<float, SK, S0, ST, 4, 2, ITWV, TYV, NTV>), g, dim3(NTV), ldsB, ctx->stream, P);    \
+		}                                                                                                                              \
 		launched = true;                                                                                                               \
 	} while (0)
 			if (arith && skip == 1 && sizes[0] == 9 && step == 6) {
-				if (v == 'a') LAUNCH_FIXED(1, 9, 6, 32, 44);
-				else if (v == 'x') LAUNCH_FIXED(1, 9, 6, 32, 16);
-				else LAUNCH_FIXED(1, 9, 6, 32, 28);   // 28x28 outputs: the (28+4) x 32 intensity tile is exactly 4 passes of 256 threads
+				if (v == 'a') LAUNCH_FIXED(1, 9, 6, 32, 44, 256);
+				else if (v == 'x') LAUNCH_FIXED(1, 9, 6, 32, 16, 256);
+				else if (v == 'y') LAUNCH_FIXED(1, 9, 6, 32, 60, 512);
+				else if (v == 'z') LAUNCH_FIXED(1, 9, 6, 32, 44, 512);
+				else LAUNCH_FIXED(1, 9, 6, 32, 28, 256);   // 28x28 outputs: the (28+4) x 32 intensity tile is exactly 4 passes of 256 threads
 			} else if (arith && skip == 2 && sizes[0] == 15 && step == 12) {
-				if (v == 'a') LAUNCH_FIXED(2, 15, 12, 32, 12);
-				else if (v == 'x') LAUNCH_FIXED(2, 15, 12, 32, 20);
-				else LAUNCH_FIXED(2, 15, 12, 32, 16);
+				if (v == 'a') LAUNCH_FIXED(2, 15, 12, 32, 12, 256);
+				else if (v == 'x') LAUNCH_FIXED(2, 15, 12, 32, 20, 256);
+				else if (v == 'b') LAUNCH_FIXED(2, 15, 12, 32, 16, 256);   // round-1 shape: 28x16 outputs, four waves
+				else if (v == 'w') LAUNCH_FIXED(2, 15, 12, 32, 32, 512);
+				else if (v == 'z') LAUNCH_FIXED(2, 15, 12, 32, 24, 512);
+				// 28x40 outputs on eight waves (the tallest tile that leaves two workgroups per CU): 14 staged floats per output instead of 22.9,
+				// halo rows 44/40 instead of 20/16, 16 waves per CU instead of 12 -- 3.98 -> 3.17 ms
+				else LAUNCH_FIXED(2, 15, 12, 32, 40, 512);
 			}
 #undef LAUNCH_FIXED
 		}
