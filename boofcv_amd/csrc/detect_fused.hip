@@ -829,8 +829,6 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 #ifdef BHIP_EXPERIMENTS
 			const char* var = getenv("BHIP_FUSED_VARIANT");   // tile-shape experiments
 			const char v = var ? var[0] : 0;
-#else
-			const char v = 0;
 #endif
 #define LAUNCH_FIXED(SK, S0, ST, ITWV, TYV, NTV)                                                                                        \
 	do {                                                                                                                               \
@@ -849,20 +847,27 @@ int bhip_launch_detect_fused(bhip_ctx* ctx, ImgView ii, int batch, int skip, int
 		launched = true;                                                                                                               \
 	} while (0)
 			if (arith && skip == 1 && sizes[0] == 9 && step == 6) {
+#ifdef BHIP_EXPERIMENTS   // tile-shape experiments (scripts/variants_fused.sh); the shipped library holds the chosen shapes only
 				if (v == 'a') LAUNCH_FIXED(1, 9, 6, 32, 44, 256);
 				else if (v == 'x') LAUNCH_FIXED(1, 9, 6, 32, 16, 256);
 				else if (v == 'y') LAUNCH_FIXED(1, 9, 6, 32, 60, 512);
+				else if (v == 'w') LAUNCH_FIXED(1, 9, 6, 32, 28, 512);
 				else if (v == 'z') LAUNCH_FIXED(1, 9, 6, 32, 44, 512);
-				else LAUNCH_FIXED(1, 9, 6, 32, 28, 256);   // 28x28 outputs: the (28+4) x 32 intensity tile is exactly 4 passes of 256 threads
+				else
+#endif
+				LAUNCH_FIXED(1, 9, 6, 32, 28, 256);   // 28x28 outputs: the (28+4) x 32 intensity tile is exactly 4 passes of 256 threads
 			} else if (arith && skip == 2 && sizes[0] == 15 && step == 12) {
+#ifdef BHIP_EXPERIMENTS
 				if (v == 'a') LAUNCH_FIXED(2, 15, 12, 32, 12, 256);
 				else if (v == 'x') LAUNCH_FIXED(2, 15, 12, 32, 20, 256);
 				else if (v == 'b') LAUNCH_FIXED(2, 15, 12, 32, 16, 256);   // round-1 shape: 28x16 outputs, four waves
 				else if (v == 'w') LAUNCH_FIXED(2, 15, 12, 32, 32, 512);
 				else if (v == 'z') LAUNCH_FIXED(2, 15, 12, 32, 24, 512);
+				else
+#endif
 				// 28x40 outputs on eight waves (the tallest tile that leaves two workgroups per CU): 14 staged floats per output instead of 22.9,
-				// halo rows 44/40 instead of 20/16, 16 waves per CU instead of 12 -- 3.98 -> 3.17 ms
-				else LAUNCH_FIXED(2, 15, 12, 32, 40, 512);
+				// halo rows 44/40 instead of 20/16, 16 waves per CU instead of 12 -- 3.98 -> 3.1 ms
+				LAUNCH_FIXED(2, 15, 12, 32, 40, 512);
 			}
 #undef LAUNCH_FIXED
 		}
