@@ -73,23 +73,32 @@ __device__ __forceinline__ int scaleExp(float maxN) {
 }
 
 // ---- squared norms (fp32, rounded up); flags[0] = non-finite seen, flags[1] = max norm (float bits, non-negative) ----
-// 16 lanes per row, 4 consecutive values (two 16-byte loads) per lane
+// 16 lanes per row, 4 consecutive values (two 16-byte loads) per lane; a lane group takes PREP_ROWS rows with all their loads in flight
+#define PREP_ROWS 4
 __global__ __launch_bounds__(256) void k_assoc_norms(const double* __restrict__ D, long long rows, float* __restrict__ nrm, int* __restrict__ flags) {
-	const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+	const long long row0 = (((long long)blockIdx.x * 256 + threadIdx.x) >> 4) * PREP_ROWS;
 	const int part = threadIdx.x & 15;
-	if (row >= rows) return;   // whole 16-lane groups leave together
-	const double2* src = (const double2*)(D + row * 64 + 4 * part);
-	const double2 v0 = src[0], v1 = src[1];
-	double s = (v0.x * v0.x + v0.y * v0.y) + (v1.x * v1.x + v1.y * v1.y);
+	if (row0 >= rows) return;   // whole 16-lane groups leave together
+	double2 v0[PREP_ROWS], v1[PREP_ROWS];
 #pragma unroll
-	for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-	if (part == 0) {
-		const float n = (float)s;
-		const float nUp = n * (1.0f + 4.0f * 5.9604644775390625e-08f);   // rounded up: a band computed from it can only grow
-		nrm[row] = nUp;
-		// one hot word for the whole launch: only touch it when this row actually raises the maximum (a handful of times per launch)
-		if (!(s < 1e30)) atomicOr(&flags[0], 1);  // NaN, Inf or absurdly large: use the exact path
-		else if (__float_as_int(nUp) > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[1], __float_as_int(nUp));
+	for (int q = 0; q < PREP_ROWS; q++) {
+		const long long row = min(row0 + q, rows - 1);
+		const double2* src = (const double2*)(D + row * 64 + 4 * part);
+		v0[q] = src[0]; v1[q] = src[1];
+	}
+#pragma unroll
+	for (int q = 0; q < PREP_ROWS; q++) {
+		double s = (v0[q].x * v0[q].x + v0[q].y * v0[q].y) + (v1[q].x * v1[q].x + v1[q].y * v1[q].y);
+#pragma unroll
+		for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+		if (part == 0 && row0 + q < rows) {
+			const float n = (float)s;
+			const float nUp = n * (1.0f + 4.0f * 5.9604644775390625e-08f);   // rounded up: a band computed from it can only grow
+			nrm[row0 + q] = nUp;
+			// one hot word for the whole launch: only touch it when this row actually raises the maximum (a handful of times per launch)
+			if (!(s < 1e30)) atomicOr(&flags[0], 1);  // NaN, Inf or absurdly large: use the exact path
+			else if (__float_as_int(nUp) > __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&flags[1], __float_as_int(nUp));
+		}
 	}
 }
 
@@ -97,22 +106,33 @@ __global__ __launch_bounds__(256) void k_assoc_norms(const double* __restrict__ 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_assoc_half(const double* __restrict__ D, long long rows, float* __restrict__ nrm, const int* __restrict__ flags,
 													  _Float16* __restrict__ Hrow) {
-	const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+	const long long row0 = (((long long)blockIdx.x * 256 + threadIdx.x) >> 4) * PREP_ROWS;
 	const int part = threadIdx.x & 15;
-	if (row >= rows) return;
-	const int q = scaleExp(__int_as_float(flags[1]));
-	const double2* src = (const double2*)(D + row * 64 + 4 * part);
-	const double2 v0 = src[0], v1 = src[1];
-	_Float16* out = Hrow + row * (ROW_CHUNKS * 8);
-	const h16x4 hv = {(_Float16)(float)ldexp(v0.x, -q), (_Float16)(float)ldexp(v0.y, -q), (_Float16)(float)ldexp(v1.x, -q), (_Float16)(float)ldexp(v1.y, -q)};
-	*(h16x4*)(out + 4 * part) = hv;
-	if (part == 0) {
-		const float n = ldexpf(nrm[row], -2 * q);
-		const _Float16 hi = (_Float16)n;
-		const _Float16 lo = (_Float16)(n - (float)hi);
-		const h16x8 e = {hi, lo, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-		*(h16x8*)(out + 64) = e;
-		nrm[row] = n;
+	if (row0 >= rows) return;
+	const int q_ = scaleExp(__int_as_float(flags[1]));
+	double2 v0[PREP_ROWS], v1[PREP_ROWS];
+#pragma unroll
+	for (int q = 0; q < PREP_ROWS; q++) {
+		const long long row = min(row0 + q, rows - 1);
+		const double2* src = (const double2*)(D + row * 64 + 4 * part);
+		v0[q] = src[0]; v1[q] = src[1];
+	}
+#pragma unroll
+	for (int q = 0; q < PREP_ROWS; q++) {
+		const long long row = row0 + q;
+		if (row >= rows) break;
+		_Float16* out = Hrow + row * (ROW_CHUNKS * 8);
+		const h16x4 hv = {(_Float16)(float)ldexp(v0[q].x, -q_), (_Float16)(float)ldexp(v0[q].y, -q_), (_Float16)(float)ldexp(v1[q].x, -q_),
+						  (_Float16)(float)ldexp(v1[q].y, -q_)};
+		*(h16x4*)(out + 4 * part) = hv;
+		if (part == 0) {
+			const float n = ldexpf(nrm[row], -2 * q_);
+			const _Float16 hi = (_Float16)n;
+			const _Float16 lo = (_Float16)(n - (float)hi);
+			const h16x8 e = {hi, lo, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+			*(h16x8*)(out + 64) = e;
+			nrm[row] = n;
+		}
 	}
 }
 
@@ -524,7 +544,7 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	float* nD = shared ? nS : W.nrmD.as<float>();
 	{
 		ProfScope ps(ctx, "k_assoc_prep", (double)(rowsS + (shared ? 0 : maxDstRow)) * (2 * 64 * 8 + ROW_CHUNKS * 16));
-		const unsigned gS = (unsigned)((rowsS + 15) / 16), gD = (unsigned)((maxDstRow + 15) / 16);
+		const unsigned gS = (unsigned)((rowsS + 16 * PREP_ROWS - 1) / (16 * PREP_ROWS)), gD = (unsigned)((maxDstRow + 16 * PREP_ROWS - 1) / (16 * PREP_ROWS));
 		hipLaunchKernelGGL(k_assoc_norms, dim3(gS), dim3(256), 0, st, dev_src, rowsS, nS, flags);
 		if (!shared) hipLaunchKernelGGL(k_assoc_norms, dim3(gD), dim3(256), 0, st, dev_dst, maxDstRow, nD, flags);
 		hipLaunchKernelGGL(k_assoc_half, dim3(gS), dim3(256), 0, st, dev_src, rowsS, nS, flags, Hs);
