@@ -74,7 +74,7 @@ __device__ __forceinline__ int scaleExp(float maxN) {
 
 // ---- squared norms (fp32, rounded up); flags[0] = non-finite seen, flags[1] = max norm (float bits, non-negative) ----
 // 16 lanes per row, 4 consecutive values (two 16-byte loads) per lane; a lane group takes PREP_ROWS rows with all their loads in flight
-#define PREP_ROWS 4
+#define PREP_ROWS 8
 __global__ __launch_bounds__(256) void k_assoc_norms(const double* __restrict__ D, long long rows, float* __restrict__ nrm, int* __restrict__ flags) {
 	const long long row0 = (((long long)blockIdx.x * 256 + threadIdx.x) >> 4) * PREP_ROWS;
 	const int part = threadIdx.x & 15;
