@@ -126,7 +126,7 @@ struct NmsParams {
 };
 
 #define VSURV 64      // maxima per pass of k_nms_scalespace that wait for an evaluated outer level (such a pass tests 64 candidates)
-#define NMS_ROWS 4   // rows per thread: the column neighbours are shared and the grid has 4x fewer, longer-lived blocks
+#define NMS_ROWS 8   // rows per thread: the column neighbours are shared and the grid has 8x fewer, longer-lived blocks (4: 0.63 ms, 8: 0.49 ms, 16: 0.48 ms)
 __device__ __forceinline__ void emitKeyPoint(const NmsParams& P, int img, int x, int y, KeyPoint kp) {
 	const int b = P.p.border, step = P.radius + 1;
 	const unsigned int bit = P.p.bitBase + (unsigned)((y - b) / step) * (unsigned)P.p.nbx + (unsigned)((x - b) / step);
