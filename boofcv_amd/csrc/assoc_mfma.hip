@@ -586,8 +586,10 @@ int bhip_assoc_l2_mfma_batched(bhip_ctx* ctx, AssocMfmaWork& W, const double* de
 	}
 	{
 		ProfScope ps(ctx, "k_assoc_exact");
-		hipLaunchKernelGGL(k_assoc_exact, dim3(1024), dim3(256), 0, st, dev_src, dev_dst, A.probs, A.cand, counters, cap, rowBest, colBest);
-		hipLaunchKernelGGL(k_assoc_argsel, dim3(1024), dim3(256), 0, st, A.probs, A.cand, counters, cap, rowBest, colBest, rowArg, colArg, colCnt);
+		// about one listed pair per thread (the list length is only known on the device: 2.3 per row is typical, the grid-stride loop takes the rest)
+		const unsigned exactBlocks = (unsigned)std::min<long long>(16384, std::max<long long>(256, (3 * (rowTotal + colTotal) / 2 + 255) / 256));
+		hipLaunchKernelGGL(k_assoc_exact, dim3(exactBlocks), dim3(256), 0, st, dev_src, dev_dst, A.probs, A.cand, counters, cap, rowBest, colBest);
+		hipLaunchKernelGGL(k_assoc_argsel, dim3(exactBlocks), dim3(256), 0, st, A.probs, A.cand, counters, cap, rowBest, colBest, rowArg, colArg, colCnt);
 	}
 	// degenerate inputs? (one small read-back; the result kernels below are only trusted when the flags are clean)
 	BHIP_HIP(ctx, hipMemcpyAsync(ctx->hostScratch, flags, 16, hipMemcpyDeviceToHost, st));
