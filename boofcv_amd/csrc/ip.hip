@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void k_grad(GradParams P) {
 // Streaming form: a wave walks GR_ROWS rows of a 256-column strip; lane l owns columns 4l .. 4l+3 and keeps a three-row window in
 // registers, so every input row is loaded once per strip (16 bytes per lane); the two columns beside a lane's four come from the
 // neighbouring lanes, the strip's outermost two from single loads.  Outputs leave as 16-byte stores.  HBM: 4P read + 8P written.
-#define GR_ROWS 16
+#define GR_ROWS 8
 struct GradRow { float v[6]; };   // columns x-1 .. x+4 of one row (0 outside the image)
 __device__ __forceinline__ GradRow gradLoadRow(const GradParams& P, const float* img, int x, int y, int lane) {
 	GradRow r;
