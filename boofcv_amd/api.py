@@ -13,8 +13,11 @@ tests read like the reference's own tests; every call runs hand-written HIP kern
 Errors: BHIP_ERR_INVALID -> IllegalArgumentException, everything else -> RuntimeError (which is what a BOverride hook throws to make the
 reference fall back to its Java code).
 """
+import atexit
 import ctypes as C
 import math
+import sys
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -40,8 +43,13 @@ def _check(ctx, status):
 
 
 class Context:
-    """bhip_ctx: one per host thread per device."""
+    """bhip_ctx: one per host thread per device.
+
+    Lifetime: close() (or garbage collection) destroys the native context after closing every detect+describe object created on it; the
+    native library tolerates any order anyway (include/boofhip.h, "handles may be destroyed in any order").  At interpreter exit an
+    atexit hook closes every live context while the HIP runtime is still up; finalisers that run later do nothing."""
     _default = {}
+    _live = weakref.WeakSet()
 
     def __init__(self, device=0, stream=None):
         L = _lib.load()
@@ -54,6 +62,8 @@ class Context:
             raise RuntimeError("bhip_ctx_create(device=%d) failed with status %d: no usable MI355X? (there is no CPU fallback)" % (device, st))
         self._h = h
         self.device = device
+        self._children = weakref.WeakSet()
+        Context._live.add(self)
 
     def synchronize(self):
         _check(self, _lib.load().bhip_ctx_synchronize(self._h))
@@ -83,20 +93,36 @@ class Context:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
             _lib.load().bhip_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return   # the atexit hook below has closed what was alive; the native library ignores destroy calls after exit began
         try:
             self.close()
         except Exception:
             pass
 
     @classmethod
+    def _close_all(cls):
+        for ctx in list(cls._live):
+            try:
+                ctx.close()
+            except Exception:
+                pass
+        cls._default.clear()
+
+    @classmethod
     def default(cls, device=0):
         if device not in cls._default:
             cls._default[device] = Context(device)
         return cls._default[device]
+
+
+atexit.register(Context._close_all)   # runs before module teardown and before the HIP runtime's own exit handlers
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -405,16 +431,23 @@ class DetectDescribePoint:
         h = C.c_void_p()
         _check(self.ctx, L.bhip_surf_create(self.ctx._h, C.byref(fh), C.byref(sd), C.byref(oc), 1 if stable else 0, C.byref(h)))
         self._h = h
+        self.ctx._children.add(self)
         self._dof = L.bhip_surf_dof(h)
         self._batch = 0
         self._image = 0
         self._cache = {}
 
+    def close(self):
+        """Releases the native object (idempotent; safe after its context has been closed)."""
+        if self._h:
+            _lib.load().bhip_surf_destroy(self._h)
+            self._h = None
+
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
-            if self._h:
-                _lib.load().bhip_surf_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 

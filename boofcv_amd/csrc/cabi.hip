@@ -5,6 +5,8 @@
 #include <cfloat>
 #include <algorithm>
 #include <memory>
+#include <mutex>
+#include <unordered_set>
 
 // launchers defined in the other translation units
 int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int cap, const int* imageStart, int batch, int singleImage, long long total,
@@ -42,6 +44,28 @@ struct bhip_ctx_full : bhip_ctx {
 	CtxScratch scratch;
 };
 static CtxScratch* scratchOf(bhip_ctx* ctx) { return &static_cast<bhip_ctx_full*>(ctx)->scratch; }
+
+// Handle registry: which bhip_ctx / bhip_surf pointers are live.  The destroy calls may arrive in any order (a garbage-collected host
+// language finalises objects in no particular order; a caller may close the context first) and more than once: destroying a context
+// releases the device side of every detect+describe object created on it and leaves those objects as inert shells (every call on them
+// returns BHIP_ERR_INVALID, bhip_surf_destroy only frees the shell); a pointer that is not in the registry is refused instead of
+// dereferenced.  Once the process has started to exit (atexit) the destroy calls touch neither the HIP runtime nor the handles -- the
+// runtime's own teardown may already have run.  The registry is a leaked singleton so it outlives every static destructor.
+struct HandleRegistry {
+	std::mutex m;
+	std::unordered_set<bhip_ctx*> ctxs;
+	std::unordered_set<bhip_surf*> surfs;
+	bool exiting = false;
+};
+static HandleRegistry& registry() {
+	static HandleRegistry* r = [] {
+		HandleRegistry* p = new HandleRegistry();
+		atexit([] { registry().exiting = true; });   // registered after the HIP runtime loaded, so it runs before the runtime's teardown
+		return p;
+	}();
+	return *r;
+}
+static void surfOrphanChildren(bhip_ctx* ctx);   // registry lock held: releases the device side of every live bhip_surf created on ctx
 
 extern "C" {
 
@@ -85,6 +109,11 @@ static int ctxCreate(int device, void* stream, bool useGiven, bhip_ctx** out) {
 		delete ctx;
 		return BHIP_ERR_HIP;
 	}
+	{
+		HandleRegistry& R = registry();
+		std::lock_guard<std::mutex> lock(R.m);
+		R.ctxs.insert(ctx);
+	}
 	*out = ctx;
 	return BHIP_OK;
 }
@@ -92,9 +121,16 @@ int bhip_ctx_create(int device, bhip_ctx** out) { return ctxCreate(device, nullp
 int bhip_ctx_create_on_stream(int device, void* hip_stream, bhip_ctx** out) { return ctxCreate(device, hip_stream, true, out); }
 int bhip_ctx_destroy(bhip_ctx* c) {
 	if (!c) return BHIP_OK;
+	HandleRegistry& R = registry();
+	std::lock_guard<std::mutex> lock(R.m);
+	if (R.exiting) return BHIP_OK;                        // process teardown: the runtime reclaims everything
+	if (!R.ctxs.count(c)) return BHIP_ERR_INVALID;        // not a live context (destroyed twice, or never created)
+	R.ctxs.erase(c);
 	bhip_ctx_full* ctx = static_cast<bhip_ctx_full*>(c);
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	// detect+describe objects still alive on this context lose their device side now and become inert shells
+	surfOrphanChildren(c);
 	CtxScratch& s = ctx->scratch;
 	s.a.release(); s.b.release(); s.c.release(); s.d.release(); s.e.release(); s.work.release();
 	s.nmsBitmap.release(); s.nmsPrefix.release(); s.nmsPos.release(); s.ipTmp.release(); s.ipKernel.release();
@@ -536,7 +572,7 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, boo
 	return BHIP_OK;
 }
 
-extern "C" int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out);
+static int surfCreateUnregistered(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out);
 
 // device buffer growth that keeps the first `keep` bytes (result arrays that chunks are appended to)
 static int growKeep(bhip_ctx* ctx, DevBuf& b, size_t bytes, size_t keep) {
@@ -563,7 +599,7 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 	{ const char* e = getenv("BHIP_SURF_CHUNK"); if (e && atoi(e) > 0) chunk = atoi(e); }   // tests: chunk small batches too
 	if (batch < 2 * chunk) return BHIP_OK;
 	if (!s->worker) {
-		BHIP_TRY(bhip_surf_create(ctx, &s->det.cfg, &s->sd, &s->ori, s->stable, &s->worker));
+		BHIP_TRY(surfCreateUnregistered(ctx, &s->det.cfg, &s->sd, &s->ori, s->stable, &s->worker));
 		BHIP_HIP(ctx, hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking));
 	}
 	bhip_surf* w = s->worker;
@@ -573,12 +609,18 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 	BHIP_TRY(s->det.prepare(ctx, width, height, batch));
 	BHIP_TRY(s->iiBuf.reserve(ctx, px * 4 * batch));
 	// everything queued on the compute stream so far (an earlier batch may still read inBuf) precedes the first upload
-	hipEvent_t ev;
+	const int nchunks = (batch + chunk - 1) / chunk;
+	// events are destroyed on every way out of this function
+	struct EventSet {
+		std::vector<hipEvent_t> evs;
+		~EventSet() { for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e); }
+	} events;
+	events.evs.assign(nchunks + 1, nullptr);
+	hipEvent_t& ev = events.evs[nchunks];
+	hipEvent_t* arrived = events.evs.data();
 	BHIP_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 	BHIP_HIP(ctx, hipEventRecord(ev, ctx->stream));
 	BHIP_HIP(ctx, hipStreamWaitEvent(s->copyStream, ev, 0));
-	const int nchunks = (batch + chunk - 1) / chunk;
-	std::vector<hipEvent_t> arrived(nchunks, nullptr);
 	int status = BHIP_OK;
 	for (int c = 0; c < nchunks && status == BHIP_OK; c++) {
 		const int a = c * chunk, n = std::min(chunk, batch - a);
@@ -623,9 +665,6 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 	// every upload has to be over before the caller's frames may change (and before the plain path re-uses inBuf)
 	(void)hipStreamSynchronize(s->copyStream);
 	(void)hipStreamSynchronize(ctx->stream);
-	for (int c = 0; c < nchunks; c++)
-		if (arrived[c]) (void)hipEventDestroy(arrived[c]);
-	(void)hipEventDestroy(ev);
 	w->extII = nullptr;
 	if (status != BHIP_OK) return status;
 	if (!fits) {
@@ -649,9 +688,7 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 	return BHIP_OK;
 }
 
-extern "C" {
-
-int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out) {
+static int surfCreateUnregistered(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out) {
 	CHECK_CTX(ctx);
 	if (!out) return bhip_fail(ctx, BHIP_ERR_INVALID, "null output");
 	*out = nullptr;
@@ -662,20 +699,53 @@ int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* 
 	if (fh) s->det.cfg = *fh; else bhip_fh_cfg_default(&s->det.cfg);
 	if (surf) s->sd = *surf; else bhip_surf_cfg_default(&s->sd);
 	if (ori) s->ori = *ori; else bhip_ori_cfg_default(&s->ori, s->stable);
-	BHIP_TRY(buildTables(s.get()));
+	const int st = buildTables(s.get());
+	if (st != BHIP_OK) { s->tabBuf.release(); return st; }
 	*out = s.release();
+	return BHIP_OK;
+}
+
+// Frees everything s holds on the device (its context must still be alive) and detaches it from the context: s is an inert shell afterwards.
+// The chunk worker is owned by s and is not in the registry.
+static void surfReleaseDevice(bhip_surf* s) {
+	if (!s || !s->ctx) return;
+	(void)hipSetDevice(s->ctx->device);
+	(void)hipStreamSynchronize(s->ctx->stream);
+	if (s->worker) { surfReleaseDevice(s->worker); delete s->worker; s->worker = nullptr; }
+	if (s->copyStream) { (void)hipStreamSynchronize(s->copyStream); (void)hipStreamDestroy(s->copyStream); s->copyStream = nullptr; }
+	s->det.release();
+	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite, &s->permBuf};
+	for (DevBuf* b : bufs) b->release();
+	s->haveResult = false;
+	s->ctx = nullptr;
+}
+static void surfOrphanChildren(bhip_ctx* ctx) {
+	for (bhip_surf* s : registry().surfs)
+		if (s->ctx == ctx) surfReleaseDevice(s);
+}
+
+extern "C" {
+
+int bhip_surf_create(bhip_ctx* ctx, const bhip_fh_cfg* fh, const bhip_surf_cfg* surf, const bhip_ori_cfg* ori, int stable, bhip_surf** out) {
+	HandleRegistry& R = registry();
+	{
+		std::lock_guard<std::mutex> lock(R.m);
+		if (!ctx || !R.ctxs.count(ctx)) return BHIP_ERR_INVALID;
+	}
+	BHIP_TRY(surfCreateUnregistered(ctx, fh, surf, ori, stable, out));
+	std::lock_guard<std::mutex> lock(R.m);
+	R.surfs.insert(*out);
 	return BHIP_OK;
 }
 
 int bhip_surf_destroy(bhip_surf* s) {
 	if (!s) return BHIP_OK;
-	(void)hipSetDevice(s->ctx->device);
-	(void)hipStreamSynchronize(s->ctx->stream);
-	if (s->worker) { (void)bhip_surf_destroy(s->worker); s->worker = nullptr; }
-	if (s->copyStream) { (void)hipStreamDestroy(s->copyStream); s->copyStream = nullptr; }
-	s->det.release();
-	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite, &s->permBuf};
-	for (DevBuf* b : bufs) b->release();
+	HandleRegistry& R = registry();
+	std::lock_guard<std::mutex> lock(R.m);
+	if (R.exiting) return BHIP_OK;                       // process teardown: the runtime reclaims everything
+	if (!R.surfs.count(s)) return BHIP_ERR_INVALID;      // not a live object (destroyed twice, or never created)
+	R.surfs.erase(s);
+	surfReleaseDevice(s);                                // no-op when the context went first
 	delete s;
 	return BHIP_OK;
 }
@@ -1177,6 +1247,9 @@ int bhip_assoc_l2_surf(bhip_surf* s, int count, const int* srcImage, const int* 
 	CtxScratch* sc = scratchOf(ctx);
 	BHIP_TRY(sc->c.reserve(ctx, (size_t)total * 4));
 	BHIP_TRY(sc->e.reserve(ctx, (size_t)total * 8));
+	// rows of images that are the source of no problem in this call come back as "no match" (-1, 0), not as whatever an earlier call left
+	BHIP_HIP(ctx, hipMemsetAsync(sc->c.p, 0xff, (size_t)total * 4, ctx->stream));
+	BHIP_HIP(ctx, hipMemsetAsync(sc->e.p, 0, (size_t)total * 8, ctx->stream));
 	BHIP_TRY(bhip_assoc_l2_dev_batched(ctx, s->descBuf.as<double>(), s->descBuf.as<double>(), s->dofOut(), count, so.data(), ns.data(), doff.data(), nd.data(),
 									   maxErr, backwards, sc->c.as<int>(), sc->e.as<double>()));
 	BHIP_HIP(ctx, hipMemcpyAsync(pairs, sc->c.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));

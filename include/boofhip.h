@@ -19,7 +19,11 @@
  *  - images are GrayF32: pixel (x,y) = data[startIndex + y*stride + x]  (T:struct/image/ImageBase.java:34-52),
  *    so sub-images (startIndex != 0, stride > width) work everywhere;
  *  - pointers named dev_* are device (HBM) addresses on the ctx's device; every other pointer is host memory;
- *  - there is no CPU fallback inside the library: without a usable GPU bhip_ctx_create fails.
+ *  - there is no CPU fallback inside the library: without a usable GPU bhip_ctx_create fails;
+ *  - handles may be destroyed in any order and more than once: bhip_ctx_destroy releases the device side of every bhip_surf created on
+ *    that context (they become inert: every call on them returns BHIP_ERR_INVALID, bhip_surf_destroy then only frees the shell), a
+ *    pointer that is not a live handle is refused with BHIP_ERR_INVALID, and once the process is exiting the destroy calls do nothing
+ *    (a finaliser that runs after the HIP runtime has shut down is harmless).
  */
 #ifndef BOOFHIP_H
 #define BOOFHIP_H
@@ -107,7 +111,11 @@ int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* start
 /* same on a device-resident batch: image i starts at dev_images + i*imageStride floats, rows are `stride` floats apart.
  * Asynchronous on the ctx stream apart from one small count read-back. */
 int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long imageStride, int stride, int width, int height, int batch);
-/* getNumberOfFeatures() */
+/* The same on GrayU8 frames: the integral images are GrayS32 (GIntegralImageOps.getIntegralType) and every stage runs on integer taps --
+ * IntegralImageOps.transform(GrayU8, GrayS32), FastHessianFeatureDetector<GrayS32>, SparseIntegralGradient_NoBorder_I32 for the
+ * orientation and the descriptor, convolveSparse(GrayS32) for the Laplacian sign.  Results through the same count / fetch calls;
+ * bhip_surf_fetch_integral then returns the int32 words. */
+int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* startIndex, const int* stride, int width, int height, int batch);
 /* FactoryDetectDescribe.surfColorStable / surfColorFast (F:factory/feature/detdesc/FactoryDetectDescribe.java:154-176,246-268) on one
  * Planar<GrayF32> frame given as numBands band pointers of one shape: SurfPlanar_to_DetectDescribePoint.detect
  * (F:abst/feature/detdesc/SurfPlanar_to_DetectDescribePoint.java:62-77) = band average -> integral images of the average and of every band
@@ -115,12 +123,8 @@ int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long im
  * orientation object radius = scale) -> DescribePointSurfPlanar.describe (F:alg/feature/describe/DescribePointSurfPlanar.java:100-114;
  * bands concatenated, normalised once; Laplacian sign from the average).  Results through bhip_surf_count / _fetch / _dev_view with
  * image = 0; bhip_surf_dof() then returns numBands * 64.  getRadius(i) of this wrapper is the scale itself (no factor 2). */
-/* The same on GrayU8 frames: the integral images are GrayS32 (GIntegralImageOps.getIntegralType) and every stage runs on integer taps --
- * IntegralImageOps.transform(GrayU8, GrayS32), FastHessianFeatureDetector<GrayS32>, SparseIntegralGradient_NoBorder_I32 for the
- * orientation and the descriptor, convolveSparse(GrayS32) for the Laplacian sign.  Results through the same count / fetch calls;
- * bhip_surf_fetch_integral then returns the int32 words. */
-int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* startIndex, const int* stride, int width, int height, int batch);
 int bhip_surf_detect_planar_f32(bhip_surf* s, const float* const* bands, int numBands, int startIndex, int stride, int width, int height);
+/* getNumberOfFeatures() of image `image` of the last detect */
 int bhip_surf_count(bhip_surf* s, int image, int* n);
 /* getLocation(i)/scale -> xy_scale[3n] ; getOrientation(i) -> angle[n] ; BrightFeature.white -> white[n] ;
  * getDescription(i).value -> desc[64n].  getRadius(i) = scale*2 (BoofDefaults.SURF_SCALE_TO_RADIUS).  Any pointer may be NULL. */
@@ -132,7 +136,7 @@ int bhip_surf_fetch_all(bhip_surf* s, double* xy_scale, double* angle, uint8_t* 
  * AssociateDescription.java:42-61 with lists a provider recognises as its own getDescription() objects): problem p associates image
  * srcImage[p] (source) with image dstImage[p] (destination), ScoreAssociateEuclideanSq_F64, same rules and results as bhip_assoc_l2_f64, no
  * descriptor upload.  pairs / fit: host arrays of bhip_surf_total entries; problem p's results start at the exclusive prefix of the counts
- * of srcImage[p] (an image may be the source of one problem per call); entries of images that are no source are unspecified. */
+ * of srcImage[p] (an image may be the source of one problem per call); entries of images that are no source read -1 / 0.0. */
 int bhip_assoc_l2_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit);
 /* device views of the same results (valid until the next detect): descriptors [n][dof] doubles, laplacian signs [n] bytes */
 int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const double** dev_xy_scale, const uint8_t** dev_white, int* n);
