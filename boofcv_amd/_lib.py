@@ -61,6 +61,10 @@ SIGNATURES = {
     "bhip_surf_fetch": (_i, [_vp, _i, _dp, _dp, _u8p, _dp]),
     "bhip_surf_fetch_all": (_i, [_vp, _dp, _dp, _u8p, _dp]),
     "bhip_assoc_l2_surf": (_i, [_vp, _i, _ip, _ip, _d, _i, _ip, _dp]),
+    "bhip_surf_create_brief": (_i, [_vp, P(FhCfg), _i, _i, _i32p, _i32p, P(_vp)]),
+    "bhip_surf_fetch_brief": (_i, [_vp, _i, _i32p]),
+    "bhip_surf_dev_view_brief": (_i, [_vp, _i, P(_vp), _ip, _ip]),
+    "bhip_assoc_hamming_surf": (_i, [_vp, _i, _ip, _ip, _d, _i, _ip, _dp]),
     "bhip_surf_dev_view": (_i, [_vp, _i, P(_vp), P(_vp), P(_vp), _ip]),
     "bhip_surf_dof": (_i, [_vp]),
     "bhip_surf_total": (_i, [_vp, _llp]),

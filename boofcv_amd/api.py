@@ -647,7 +647,255 @@ class SurfPlanar_to_DetectDescribePoint(DetectDescribePoint):
         return float(self._results()[0][featureIndex][2])   # DetectDescribeSurfPlanar.getRadius: the scale itself
 
 
+class Random:
+    """java.util.Random (the JDK's documented linear congruential generator; host-side, needed only to build the BRIEF definition the way
+    FactoryBriefDefinition does).  nextGaussian uses math.log / math.sqrt where Java uses StrictMath: the table is *parity unpinned* in the
+    last ulp of log -- a Java caller passes the definition its own JVM generated."""
+
+    def __init__(self, seed):
+        self.seed = (int(seed) ^ 0x5DEECE66D) & ((1 << 48) - 1)
+        self._next_gaussian = None
+
+    def next(self, bits):
+        self.seed = (self.seed * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        v = self.seed >> (48 - bits)
+        return v - (1 << 32) if v >= (1 << 31) and bits == 32 else v
+
+    def nextInt(self, bound=None):
+        if bound is None:
+            return self.next(32)
+        if bound <= 0:
+            raise IllegalArgumentException("bound must be positive")
+        if (bound & -bound) == bound:
+            return (bound * self.next(31)) >> 31
+        while True:
+            bits = self.next(31)
+            val = bits % bound
+            if bits - val + (bound - 1) < (1 << 31):
+                return val
+
+    def nextDouble(self):
+        return ((self.next(26) << 27) + self.next(27)) * (1.0 / (1 << 53))
+
+    def nextGaussian(self):
+        if self._next_gaussian is not None:
+            g, self._next_gaussian = self._next_gaussian, None
+            return g
+        while True:
+            v1 = 2 * self.nextDouble() - 1
+            v2 = 2 * self.nextDouble() - 1
+            s = v1 * v1 + v2 * v2
+            if 0 < s < 1:
+                break
+        m = math.sqrt(-2 * math.log(s) / s)
+        self._next_gaussian = v2 * m
+        return v1 * m
+
+
+class BinaryCompareDefinition_I32:
+    """F:alg/feature/describe/brief/BinaryCompareDefinition_I32.java: sample points (x,y) and the index pairs that are compared."""
+
+    def __init__(self, radius, samplePoints, compare):
+        self.radius = int(radius)
+        self.samplePoints = np.ascontiguousarray(samplePoints, dtype=np.int32).reshape(-1, 2)
+        self.compare = np.ascontiguousarray(compare, dtype=np.int32).reshape(-1, 2)
+
+    def getLength(self):
+        return len(self.compare)
+
+
+class FactoryBriefDefinition:
+    @staticmethod
+    def gaussian2(rand, radius, numPairs):
+        """F:alg/feature/describe/brief/FactoryBriefDefinition.java:57-85: sample i = (int)(gaussian * sigma) per axis, redrawn until it lies
+        inside the circle; compare[i] = (i, rand.nextInt(numPairs)); the RNG calls interleave exactly as in the reference."""
+        sigma = (2.0 * radius + 1.0) / 5.0
+        pts = np.zeros((numPairs, 2), dtype=np.int32)
+        cmp_ = np.zeros((numPairs, 2), dtype=np.int32)
+        for i in range(numPairs):
+            while True:
+                x = int(rand.nextGaussian() * sigma)
+                y = int(rand.nextGaussian() * sigma)
+                if math.sqrt(x * x + y * y) < radius:
+                    break
+            pts[i] = (x, y)
+            cmp_[i] = (i, rand.nextInt(numPairs))
+        return BinaryCompareDefinition_I32(radius, pts, cmp_)
+
+
+@dataclass
+class ConfigBrief:
+    """F:abst/feature/describe/ConfigBrief.java:33-52"""
+    radius: int = 16
+    numPoints: int = 512
+    blurSigma: float = -1
+    blurRadius: int = 4
+    fixed: bool = True
+
+    def checkValidity(self):
+        pass
+
+
+class WrapDescribeBrief:
+    """DescribeRegionPoint<T,TupleDesc_B> (F:abst/feature/describe/WrapDescribeBrief.java:30-86) over DescribePointBrief: process() ignores
+    orientation and radius and always succeeds."""
+
+    def __init__(self, definition, imageType, ctx=None):
+        self.definition = definition
+        self.imageType = imageType
+        self.length = definition.getLength()
+        self.alg = DescribePointBrief(definition.radius, definition.samplePoints, definition.compare, ctx=ctx)
+
+    def createDescription(self):
+        return TupleDesc_B(self.length)
+
+    def setImage(self, image):
+        self.alg.setImage(image)
+
+    def process(self, x, y, orientation, radius, storage):
+        self.alg.process(x, y, storage)
+        return True
+
+    def requiresRadius(self): return False
+    def requiresOrientation(self): return False
+    def getImageType(self): return self.imageType
+    def getDescriptionType(self): return TupleDesc_B
+    def getCanonicalWidth(self): return self.definition.radius * 2 + 1
+
+
+class FactoryDescribeRegionPoint:
+    @staticmethod
+    def brief(config=None, imageType=GrayF32, definition=None, ctx=None):
+        """F:factory/feature/describe/FactoryDescribeRegionPoint.java:187-202.  `definition` lets a caller hand in the table its JVM made
+        (FactoryBriefDefinition.gaussian2(new Random(123), radius, numPoints)); otherwise it is generated here the same way."""
+        config = config or ConfigBrief()
+        config.checkValidity()
+        if not config.fixed:
+            raise RuntimeError("the scale / orientation aware BRIEF (WrapDescribeBriefSo) is not implemented on the GPU (use the Java path)")
+        if imageType is not GrayF32 and imageType is not GrayU8:
+            raise RuntimeError("only GrayF32 and GrayU8 are implemented on the GPU (use the Java path)")
+        if definition is None:
+            definition = FactoryBriefDefinition.gaussian2(Random(123), config.radius, config.numPoints)
+        return WrapDescribeBrief(definition, imageType, ctx=ctx)
+
+
+class WrapFHtoInterestPoint:
+    """InterestPointDetector over the Fast-Hessian detector (F:abst/feature/detect/interest/WrapFHtoInterestPoint.java:36-90).  On the GPU it
+    only runs fused with a describer (FactoryDetectDescribe.fuseTogether); stand-alone detection is FastHessianFeatureDetector."""
+
+    def __init__(self, config=None):
+        self.config = config or ConfigFastHessian()
+
+
+class FactoryInterestPoint:
+    @staticmethod
+    def fastHessian(config=None):
+        """F:factory/feature/detect/interest/FactoryInterestPoint.java:127-130"""
+        return WrapFHtoInterestPoint(config)
+
+
+class DetectDescribeFusion(DetectDescribePoint):
+    """DetectDescribePoint<T,TupleDesc_B> = DetectDescribeFusion(fastHessian, null, brief) (F:abst/feature/detdesc/DetectDescribeFusion.java:
+    45-165): Fast-Hessian points in detector order, every one described (WrapDescribeBrief.process always returns true), orientation 0
+    (WrapFHtoInterestPoint.getOrientation), radius = scale * 2.  Detection, BRIEF and -- through associateImages -- Hamming association run
+    on the device without the points or words leaving it (bhip_surf_create_brief)."""
+
+    def __init__(self, detector, describe, ctx=None):
+        self.ctx = ctx or Context.default()
+        L = _lib.load()
+        fh = detector.config._c()
+        d = describe.definition
+        self.describe = describe
+        self._words = (describe.length + 31) // 32
+        h = C.c_void_p()
+        _check(self.ctx, L.bhip_surf_create_brief(self.ctx._h, C.byref(fh), d.radius, describe.length, d.samplePoints.ctypes.data_as(_lib._i32p),
+                                                  d.compare.ctypes.data_as(_lib._i32p), C.byref(h)))
+        self._h = h
+        self.ctx._children.add(self)
+        self._dof = 0
+        self._batch = 0
+        self._image = 0
+        self._cache = {}
+
+    def createDescription(self):
+        return TupleDesc_B(self.describe.length)
+
+    def getDescriptionType(self):
+        return TupleDesc_B
+
+    def _results(self, image=None):
+        image = self._image if image is None else image
+        if image not in self._cache:
+            L = _lib.load()
+            n = C.c_int(0)
+            _check(self.ctx, L.bhip_surf_count(self._h, image, C.byref(n)))
+            n = n.value
+            xys = np.zeros((n, 3)); ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); words = np.zeros((n, self._words), dtype=np.int32)
+            if n:
+                _check(self.ctx, L.bhip_surf_fetch(self._h, image, xys.ctypes.data_as(_lib._dp), ang.ctypes.data_as(_lib._dp),
+                                                   white.ctypes.data_as(_lib._u8p), None))
+                _check(self.ctx, L.bhip_surf_fetch_brief(self._h, image, words.ctypes.data_as(_lib._i32p)))
+            self._cache[image] = (xys, ang, white, words)
+        return self._cache[image]
+
+    def fetchAll(self, out=None):
+        """(xy_scale [total,3], words [total, ceil(numPoints/32)] int32, starts [batch+1]) of the whole last batch."""
+        L = _lib.load()
+        counts = np.zeros(self._batch, dtype=np.int32)
+        n = C.c_int(0)
+        for i in range(self._batch):
+            _check(self.ctx, L.bhip_surf_count(self._h, i, C.byref(n)))
+            counts[i] = n.value
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        total = int(starts[-1])
+        xys = np.empty((total, 3)); words = np.empty((total, self._words), dtype=np.int32)
+        if total:
+            _check(self.ctx, L.bhip_surf_fetch_all(self._h, xys.ctypes.data_as(_lib._dp), None, None, None))
+            _check(self.ctx, L.bhip_surf_fetch_brief(self._h, -1, words.ctypes.data_as(_lib._i32p)))
+        return xys, words, starts
+
+    def associateImages(self, srcImages, dstImages, maxError=Double_MAX_VALUE, backwardsValidation=True):
+        """Greedy Hamming association (ScoreAssociateHamming_B) of image srcImages[p] with image dstImages[p] of the last detect, on the
+        words still resident on the device (bhip_assoc_hamming_surf)."""
+        L = _lib.load()
+        a = np.ascontiguousarray(srcImages, dtype=np.int32)
+        b = np.ascontiguousarray(dstImages, dtype=np.int32)
+        if a.shape != b.shape:
+            raise IllegalArgumentException("source and destination image lists differ in length")
+        total = max(self.totalFeatures(), 1)
+        pairs = np.full(total, -1, dtype=np.int32)
+        fit = np.zeros(total)
+        _check(self.ctx, L.bhip_assoc_hamming_surf(self._h, len(a), a.ctypes.data_as(_lib._ip), b.ctypes.data_as(_lib._ip), float(maxError),
+                                                   1 if backwardsValidation else 0, pairs.ctypes.data_as(_lib._ip), fit.ctypes.data_as(_lib._dp)))
+        return pairs, fit
+
+    def deviceViewBrief(self, image):
+        """(dev_words_ptr, ints_per_feature, n) of image `image` -- valid until the next detect."""
+        d, w, n = C.c_void_p(), C.c_int(0), C.c_int(0)
+        _check(self.ctx, _lib.load().bhip_surf_dev_view_brief(self._h, image, C.byref(d), C.byref(w), C.byref(n)))
+        return d.value, w.value, n.value
+
+    def describePoints(self, xy_scale, image=0):
+        raise RuntimeError("a fused BRIEF object describes the points it detects; use DescribePointBrief for a caller's point list")
+
+    def getOrientation(self, featureIndex):
+        return 0.0
+
+    def getDescription(self, index):
+        return TupleDesc_B(self.describe.length, self._results()[3][index])
+
+    def hasOrientation(self):
+        return False   # orientation == null -> detector.hasOrientation() (DetectDescribeFusion.java:150-155)
+
+
 class FactoryDetectDescribe:
+    @staticmethod
+    def fuseTogether(detector, orientation, describe, ctx=None):
+        """F:factory/feature/detdesc/FactoryDetectDescribe.java:279-284.  On the GPU: Fast-Hessian + (no orientation) + fixed BRIEF."""
+        if not isinstance(detector, WrapFHtoInterestPoint) or orientation is not None or not isinstance(describe, WrapDescribeBrief):
+            raise RuntimeError("only fuseTogether(fastHessian, null, brief) is implemented on the GPU (use the Java path)")
+        return DetectDescribeFusion(detector, describe, ctx=ctx)
+
     @staticmethod
     def surfColorFast(configDetector=None, configDesc=None, configOrientation=None, imageType=None, ctx=None):
         """F:factory/feature/detdesc/FactoryDetectDescribe.java:154-176"""

@@ -34,17 +34,23 @@ def build(force=False, verbose=False, experiments=False):
     """experiments=True builds libboofhip_exp.so with the timing-experiment switches compiled in (select it with BHIP_LIB=...);
     the default product library contains none of them (tests/test_cabi_symbols.py)."""
     lib = LIB_EXPERIMENTS if experiments else LIB
+    extra = []
+    if experiments and os.environ.get("BHIP_EXP_DEFS"):
+        # compile-time variants for A/B runs: BHIP_EXP_DEFS="-DBHIP_TAP_AUX=1" BHIP_EXP_TAG=sc0 -> libboofhip_exp_sc0.so
+        extra = os.environ["BHIP_EXP_DEFS"].split()
+        lib = os.path.join(HERE, "libboofhip_exp_%s.so" % os.environ.get("BHIP_EXP_TAG", "variant"))
+        force = True
     if not force and not needs_build(lib):
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    objdir = os.path.join(HERE, "build_exp" if experiments else "build")
+    objdir = os.path.join(HERE, ("build_exp_" + os.environ.get("BHIP_EXP_TAG", "variant")) if extra else "build_exp" if experiments else "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + (["-DBHIP_EXPERIMENTS"] if experiments else []) + ["-c", src, "-o", obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + (["-DBHIP_EXPERIMENTS"] if experiments else []) + extra + ["-c", src, "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")
             cmd.insert(2, "hip")

@@ -450,6 +450,15 @@ struct bhip_surf {
 	bhip_surf* worker = nullptr;
 	hipStream_t copyStream = nullptr;
 	float* extII = nullptr;    // worker only: where the integral images of the current chunk go (a slice of the owner's iiBuf)
+	// describe = BRIEF (DetectDescribeFusion(fastHessian, null, brief), bhip_surf_create_brief): no orientation / SURF stage; every detected
+	// point gets its TupleDesc_B words from the input frame itself
+	bool brief = false;
+	int briefRadius = 0, briefPoints = 0, briefWords = 0;
+	DevBuf briefTab, wordsBuf;   // [samplePoints | compare] on the device; words of the whole batch, compact [total][briefWords]
+	const int* briefBorrow = nullptr;   // chunk worker: the owner's table
+	const int* briefSample() const { return briefBorrow ? briefBorrow : briefTab.as<int>(); }
+	const int* briefCompare() const { return briefSample() + briefCompareOff; }
+	size_t briefCompareOff = 0;
 };
 
 static int buildTables(bhip_surf* s) {
@@ -542,6 +551,28 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, boo
 	if (total > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_CAPACITY, "more than 2^31 key points in one batch");
 	BHIP_TRY(s->startBuf.reserve(ctx, (size_t)(batch + 1) * 4));
 	BHIP_HIP(ctx, hipMemcpyAsync(s->startBuf.p, s->starts.data(), (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+	if (s->brief) {
+		// DetectDescribeFusion.detect (F:abst/feature/detdesc/DetectDescribeFusion.java:95-127) with orientation == null and
+		// describe = WrapDescribeBrief (process always returns true, so every detected point is kept, in detector order):
+		// yaw = detector.getOrientation(i) = 0 (WrapFHtoInterestPoint.java:77-79); DescribePointBrief.process samples the frame handed to
+		// setImage (:71-75,86-88 -- the blurred copy it makes is never read)
+		if (planarBands > 0) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "BRIEF runs on single-band frames");
+		BHIP_TRY(s->angBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8));
+		BHIP_TRY(s->whiteBuf.reserve(ctx, (size_t)std::max<long long>(total, 1)));
+		BHIP_TRY(s->wordsBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 4 * s->briefWords));
+		if (total > 0) {
+			BHIP_HIP(ctx, hipMemsetAsync(s->angBuf.p, 0, (size_t)total * 8, ctx->stream));
+			BHIP_HIP(ctx, hipMemsetAsync(s->whiteBuf.p, 0, (size_t)total, ctx->stream));
+			int maxCount = 0;
+			for (int c : s->det.counts) maxCount = std::max(maxCount, c);
+			BHIP_TRY(bhip_launch_brief(ctx, in.data, u8 ? W : in.stride, W, H, s->briefRadius, s->briefPoints, s->briefSample(), s->briefCompare(),
+									   (const double*)s->det.sorted.p, (int)total, s->wordsBuf.as<int>(), u8, batch, u8 ? (long long)W * H : in.imageStride,
+									   s->startBuf.as<int>(), maxCount, (int)(sizeof(KeyPoint) / 8), (long long)s->det.cap * (long long)(sizeof(KeyPoint) / 8)));
+		}
+		BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		s->haveResult = true;
+		return BHIP_OK;
+	}
 	const int dof = s->dofOut();
 	BHIP_TRY(s->angBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8));
 	BHIP_TRY(s->descBuf.reserve(ctx, (size_t)std::max<long long>(total, 1) * 8 * dof));
@@ -600,6 +631,12 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 	if (batch < 2 * chunk) return BHIP_OK;
 	if (!s->worker) {
 		BHIP_TRY(surfCreateUnregistered(ctx, &s->det.cfg, &s->sd, &s->ori, s->stable, &s->worker));
+		if (s->brief) {
+			// the worker samples with the owner's definition (it borrows the device table; briefTab stays empty so it is never freed twice)
+			bhip_surf* w0 = s->worker;
+			w0->brief = true; w0->briefRadius = s->briefRadius; w0->briefPoints = s->briefPoints; w0->briefWords = s->briefWords;
+			w0->briefBorrow = s->briefTab.as<int>(); w0->briefCompareOff = s->briefCompareOff;
+		}
 		BHIP_HIP(ctx, hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking));
 	}
 	bhip_surf* w = s->worker;
@@ -645,15 +682,17 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 		if (maxCount > s->det.cap) { fits = false; break; }   // the owner's [image][cap] key-point array is too narrow: plain path (it grows there)
 		const long long ct = w->det.total;
 		status = growKeep(ctx, s->angBuf, (size_t)std::max<long long>(total + ct, 1) * 8, (size_t)total * 8);
-		if (status == BHIP_OK) status = growKeep(ctx, s->descBuf, (size_t)std::max<long long>(total + ct, 1) * 8 * dof, (size_t)total * 8 * dof);
+		if (status == BHIP_OK && !s->brief) status = growKeep(ctx, s->descBuf, (size_t)std::max<long long>(total + ct, 1) * 8 * dof, (size_t)total * 8 * dof);
 		if (status == BHIP_OK) status = growKeep(ctx, s->whiteBuf, (size_t)std::max<long long>(total + ct, 1), (size_t)total);
+		if (status == BHIP_OK && s->brief) status = growKeep(ctx, s->wordsBuf, (size_t)std::max<long long>(total + ct, 1) * 4 * s->briefWords, (size_t)total * 4 * s->briefWords);
 		if (status != BHIP_OK) break;
 		hipError_t e = hipSuccess;
 		if (maxCount > 0)
 			e = hipMemcpy2DAsync(s->det.sorted.as<KeyPoint>() + (long long)a * s->det.cap, (size_t)s->det.cap * sizeof(KeyPoint), w->det.sorted.p,
 								 (size_t)w->det.cap * sizeof(KeyPoint), (size_t)maxCount * sizeof(KeyPoint), n, hipMemcpyDeviceToDevice, ctx->stream);
 		if (e == hipSuccess && ct > 0) e = hipMemcpyAsync(s->angBuf.as<double>() + total, w->angBuf.p, (size_t)ct * 8, hipMemcpyDeviceToDevice, ctx->stream);
-		if (e == hipSuccess && ct > 0) e = hipMemcpyAsync(s->descBuf.as<double>() + total * dof, w->descBuf.p, (size_t)ct * 8 * dof, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && ct > 0 && !s->brief) e = hipMemcpyAsync(s->descBuf.as<double>() + total * dof, w->descBuf.p, (size_t)ct * 8 * dof, hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess && ct > 0 && s->brief) e = hipMemcpyAsync(s->wordsBuf.as<int>() + total * s->briefWords, w->wordsBuf.p, (size_t)ct * 4 * s->briefWords, hipMemcpyDeviceToDevice, ctx->stream);
 		if (e == hipSuccess && ct > 0) e = hipMemcpyAsync(s->whiteBuf.as<uint8_t>() + total, w->whiteBuf.p, (size_t)ct, hipMemcpyDeviceToDevice, ctx->stream);
 		if (e != hipSuccess) { status = bhip_fail(ctx, BHIP_ERR_HIP, hipGetErrorString(e)); break; }
 		for (int i = 0; i < n; i++) {
@@ -714,8 +753,10 @@ static void surfReleaseDevice(bhip_surf* s) {
 	if (s->worker) { surfReleaseDevice(s->worker); delete s->worker; s->worker = nullptr; }
 	if (s->copyStream) { (void)hipStreamSynchronize(s->copyStream); (void)hipStreamDestroy(s->copyStream); s->copyStream = nullptr; }
 	s->det.release();
-	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite, &s->permBuf};
+	DevBuf* bufs[] = {&s->tabBuf, &s->inBuf, &s->iiBuf, &s->startBuf, &s->angBuf, &s->descBuf, &s->whiteBuf, &s->xysBuf, &s->tmpKp, &s->tmpAng, &s->tmpDesc, &s->tmpWhite, &s->permBuf,
+					  &s->briefTab, &s->wordsBuf};
 	for (DevBuf* b : bufs) b->release();
+	s->briefBorrow = nullptr;
 	s->haveResult = false;
 	s->ctx = nullptr;
 }
@@ -852,6 +893,7 @@ int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, ui
 	bhip_ctx* ctx = s->ctx;
 	CHECK_CTX(ctx);
 	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	if (desc && s->brief) return bhip_fail(ctx, BHIP_ERR_INVALID, "this object describes with BRIEF: fetch the words with bhip_surf_fetch_brief");
 	const int n = s->det.counts[image];
 	if (n == 0) return BHIP_OK;
 	const long long off = s->starts[image];
@@ -878,6 +920,7 @@ int bhip_surf_fetch_all(bhip_surf* s, double* xy_scale, double* angle, uint8_t* 
 	bhip_ctx* ctx = s->ctx;
 	CHECK_CTX(ctx);
 	if (!s->haveResult) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result");
+	if (desc && s->brief) return bhip_fail(ctx, BHIP_ERR_INVALID, "this object describes with BRIEF: fetch the words with bhip_surf_fetch_brief");
 	const long long total = s->det.total;
 	if (total == 0) return BHIP_OK;
 	const int dof = s->dofOut();
@@ -911,6 +954,65 @@ int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const d
 	return BHIP_OK;
 }
 
+// FactoryDetectDescribe.fuseTogether(FactoryInterestPoint.fastHessian(fh), null, FactoryDescribeRegionPoint.brief(config, imageType))
+// (F:factory/feature/detdesc/FactoryDetectDescribe.java:279-284, F:factory/feature/describe/FactoryDescribeRegionPoint.java:187-202 with
+// config.fixed): the returned object is driven through the same bhip_surf_detect_* / _count / _fetch calls as the SURF one.
+int bhip_surf_create_brief(bhip_ctx* ctx, const bhip_fh_cfg* fh, int radius, int numPoints, const int32_t* samplePoints, const int32_t* compare, bhip_surf** out) {
+	HandleRegistry& R = registry();
+	{
+		std::lock_guard<std::mutex> lock(R.m);
+		if (!ctx || !R.ctxs.count(ctx)) return BHIP_ERR_INVALID;
+	}
+	CHECK_CTX(ctx);
+	if (!out) return bhip_fail(ctx, BHIP_ERR_INVALID, "null output");
+	*out = nullptr;
+	if (radius < 0 || numPoints <= 0 || !samplePoints || !compare) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad BRIEF definition");
+	int maxIdx = 0;
+	for (int i = 0; i < 2 * numPoints; i++) {
+		if (compare[i] < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "negative sample index");
+		maxIdx = std::max(maxIdx, compare[i]);
+	}
+	bhip_surf* s = nullptr;
+	BHIP_TRY(surfCreateUnregistered(ctx, fh, nullptr, nullptr, 0, &s));   // (the SURF tables of the shell are never used)
+	s->brief = true;
+	s->briefRadius = radius; s->briefPoints = numPoints; s->briefWords = (numPoints + 31) / 32;
+	const size_t nSample = (size_t)(maxIdx + 1) * 2, nCompare = (size_t)numPoints * 2;
+	s->briefCompareOff = nSample;
+	int st = s->briefTab.reserve(ctx, (nSample + nCompare) * 4);
+	if (st == BHIP_OK && hipMemcpy(s->briefTab.p, samplePoints, nSample * 4, hipMemcpyHostToDevice) != hipSuccess) st = bhip_fail(ctx, BHIP_ERR_HIP, "BRIEF table upload");
+	if (st == BHIP_OK && hipMemcpy(s->briefTab.as<int>() + nSample, compare, nCompare * 4, hipMemcpyHostToDevice) != hipSuccess) st = bhip_fail(ctx, BHIP_ERR_HIP, "BRIEF table upload");
+	if (st != BHIP_OK) { surfReleaseDevice(s); delete s; return st; }
+	std::lock_guard<std::mutex> lock(R.m);
+	R.surfs.insert(s);
+	*out = s;
+	return BHIP_OK;
+}
+
+// getDescription(i).data of every feature of one image (image >= 0: count * words ints) or of the whole batch (image = -1: total * words
+// ints, image i's slice at the exclusive prefix of the counts); words = ceil(numPoints / 32) (TupleDesc_B, T:struct/feature/TupleDesc_B.java)
+int bhip_surf_fetch_brief(bhip_surf* s, int image, int32_t* words) {
+	if (!s || !words) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->brief) return bhip_fail(ctx, BHIP_ERR_INVALID, "not a BRIEF detect+describe object");
+	if (!s->haveResult || image < -1 || image >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	const long long off = image < 0 ? 0 : s->starts[image];
+	const long long n = image < 0 ? s->det.total : s->det.counts[image];
+	if (n == 0) return BHIP_OK;
+	BHIP_HIP(ctx, hipMemcpyAsync(words, s->wordsBuf.as<int>() + off * s->briefWords, (size_t)n * 4 * s->briefWords, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+int bhip_surf_dev_view_brief(bhip_surf* s, int image, const int32_t** dev_words, int* words, int* n) {
+	if (!s) return BHIP_ERR_INVALID;
+	if (!s->brief) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "not a BRIEF detect+describe object");
+	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	if (dev_words) *dev_words = s->wordsBuf.as<int>() + (long long)s->starts[image] * s->briefWords;
+	if (words) *words = s->briefWords;
+	if (n) *n = s->det.counts[image];
+	return BHIP_OK;
+}
+
 int bhip_surf_fetch_integral(bhip_surf* s, int image, float* out) {
 	if (!s || !out) return BHIP_ERR_INVALID;
 	bhip_ctx* ctx = s->ctx;
@@ -926,6 +1028,7 @@ int bhip_surf_describe_points(bhip_surf* s, int image, const double* xy_scale, i
 	bhip_ctx* ctx = s->ctx;
 	CHECK_CTX(ctx);
 	if (!s->haveResult || image < 0 || image >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result for that image");
+	if (s->brief) return bhip_fail(ctx, BHIP_ERR_INVALID, "this object describes with BRIEF");
 	if (n < 0 || (n > 0 && !xy_scale)) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad point list");
 	if (n == 0) return BHIP_OK;
 	std::vector<KeyPoint> kps(n);
@@ -1224,10 +1327,47 @@ int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double
 // recognises as its own): problem p associates image srcImage[p] (source) with image dstImage[p] (destination) -- same rules as
 // bhip_assoc_l2_f64, no descriptor upload.  pairs / fit are host arrays over the compact key-point index space of the batch: the results
 // of problem p start at the exclusive prefix of the counts of srcImage[p] (every image may be a source at most once per call).
+// AssociateDescription<TupleDesc_B>.associate() with ScoreAssociateHamming_B on the words still resident from the last detect of a BRIEF
+// object: same contract as bhip_assoc_l2_surf, same rules and results as bhip_assoc_hamming, no descriptor upload.
+int bhip_assoc_hamming_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit) {
+	if (!s) return BHIP_ERR_INVALID;
+	bhip_ctx* ctx = s->ctx;
+	CHECK_CTX(ctx);
+	if (!s->brief) return bhip_fail(ctx, BHIP_ERR_INVALID, "not a BRIEF detect+describe object");
+	if (!s->haveResult) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result");
+	if (count < 0 || (count > 0 && (!srcImage || !dstImage || !pairs || !fit))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad problem table");
+	if (count == 0) return BHIP_OK;
+	const long long total = s->det.total;
+	std::vector<char> used(s->batch, 0);
+	for (int p = 0; p < count; p++) {
+		const int a = srcImage[p], b = dstImage[p];
+		if (a < 0 || a >= s->batch || b < 0 || b >= s->batch) return bhip_fail(ctx, BHIP_ERR_INVALID, "image index outside the last batch");
+		if (used[a]) return bhip_fail(ctx, BHIP_ERR_INVALID, "an image may be the source of one problem per call");
+		used[a] = 1;
+	}
+	if (total == 0) return BHIP_OK;
+	CtxScratch* sc = scratchOf(ctx);
+	BHIP_TRY(sc->c.reserve(ctx, (size_t)total * 4));
+	BHIP_TRY(sc->e.reserve(ctx, (size_t)total * 8));
+	BHIP_HIP(ctx, hipMemsetAsync(sc->c.p, 0xff, (size_t)total * 4, ctx->stream));
+	BHIP_HIP(ctx, hipMemsetAsync(sc->e.p, 0, (size_t)total * 8, ctx->stream));
+	const int32_t* W = s->wordsBuf.as<int32_t>();
+	for (int p = 0; p < count; p++) {
+		const int a = srcImage[p], b = dstImage[p];
+		BHIP_TRY(bhip_assoc_hamming_dev(ctx, W + (long long)s->starts[a] * s->briefWords, s->det.counts[a], W + (long long)s->starts[b] * s->briefWords,
+										s->det.counts[b], s->briefWords, maxErr, backwards, sc->c.as<int>() + s->starts[a], sc->e.as<double>() + s->starts[a]));
+	}
+	BHIP_HIP(ctx, hipMemcpyAsync(pairs, sc->c.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipMemcpyAsync(fit, sc->e.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BHIP_OK;
+}
+
 int bhip_assoc_l2_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit) {
 	if (!s) return BHIP_ERR_INVALID;
 	bhip_ctx* ctx = s->ctx;
 	CHECK_CTX(ctx);
+	if (s->brief) return bhip_fail(ctx, BHIP_ERR_INVALID, "this object describes with BRIEF: use bhip_assoc_hamming_surf");
 	if (!s->haveResult) return bhip_fail(ctx, BHIP_ERR_INVALID, "no detect result");
 	if (count < 0 || (count > 0 && (!srcImage || !dstImage || !pairs || !fit))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad problem table");
 	if (count == 0) return BHIP_OK;

@@ -56,6 +56,9 @@ struct DescParams {
 	unsigned long long* stamps; // diagnostic build only: [total][16] cycle stamps
 	int sort64;               // BHIP_DESCRIBE_SORT64=1: always sort on the fp64 keys (cross-check of the 32-bit key sort)
 	int serialOnly;           // BHIP_DESCRIBE_SERIAL=1: always run the reference's serial window sweep (cross-check of the parallel form)
+#ifdef BHIP_EXPERIMENTS
+	int stopAfter;            // BHIP_DESCRIBE_STOP=k: waves return at phase boundary k (instruction counts per phase by difference; results are garbage)
+#endif
 };
 
 #define ORI_EPL_MAX 8     // orientation samples per lane (n <= 512, i.e. radius <= 10)
@@ -68,58 +71,82 @@ __device__ __forceinline__ int gradRadius(double width) {
 	if (r <= 0) r = 1;
 	return r;
 }
-// branch-free guarded sample: taps are always fetched (from (safe, safe) when the kernel leaves the image), the result is zeroed
-// afterwards.  `anyInside` is false when the image is smaller than the kernel (then every sample is zero and nothing is read).
-struct GradGeom {
-	int r, w, stride, W, H;
-	int safe;        // an in-bounds centre coordinate: r + 1
-	bool anyInside;  // 2r + 2 <= min(W, H)
-};
-__device__ __forceinline__ GradGeom makeGeom(int r, int stride, int W, int H) {
-	GradGeom g;
-	g.r = r; g.w = 2 * r + 1; g.stride = stride; g.W = W; g.H = H; g.safe = r + 1;
-	g.anyInside = (2 * r + 2 <= W) && (2 * r + 2 <= H);
-	return g;
-}
+// Branch-free guarded sample.  The 12 taps of a sample sit at wave-uniform distances from its top-left tap (they depend on the kernel
+// radius and the row pitch only), so the wave keeps ten uniform base pointers -- image base + tap distance -- in scalar registers and every
+// access of a sample uses the same per-lane byte offset: one address computation per sample instead of one per tap.  A sample whose
+// kernel leaves the image (or a lane that is switched off) reads offset 0 -- the top-left tap of the sample at (r+1, r+1), always inside
+// when anything is -- and is zeroed afterwards; `anyInside` is false when the image is smaller than the kernel (then every distance is 0:
+// only element 0 of the image is ever read, and every sample is zero).
 // T = float (GrayF32 integral image: SparseIntegralGradient_NoBorder_F32) or int (GrayS32, the integral image of a GrayU8 frame:
 // SparseIntegralGradient_NoBorder_I32.java:46-76 -- integer box differences, handed on as exact values).
-// A sample is taken in two steps so that a whole batch of samples has its 12 x batch loads in flight before the first one is waited for:
-// gradFetch issues the taps with NO control flow (a sample that is switched off, or whose kernel leaves the image, reads the safe position
-// instead; an image smaller than the kernel collapses every offset to 0), gradFinish combines them in the reference's order.
+// A sample is taken in two steps so that a whole batch of samples has its 10 x batch loads in flight before the first one is waited for:
+// gradFetch issues the taps with NO control flow, gradFinish combines them in the reference's order.
 template <class T>
 struct __attribute__((packed, aligned(4))) Pair2 { T x, y; };   // two neighbouring taps, any 4-byte alignment
+template <class T>
+struct TapBases {
+	// rows y-r-1 (a), y-1 (c1), y (c2), y+r (b); columns x-r-1 (0), x-1 and x (1: fetched as a pair), x+r (3)
+	const char *a0, *a1, *a3, *c10, *c13, *c20, *c23, *b0, *b1, *b3;
+	unsigned int r1;      // r + 1
+	unsigned int spanX;   // W - 2r - 1: a kernel is inside iff (unsigned)(x - r - 1) < spanX && (unsigned)(y - r - 1) < spanY
+	unsigned int spanY;
+	unsigned int pitch4;  // row pitch in bytes (0 when !anyInside)
+	bool anyInside;       // 2r + 2 <= min(W, H)
+};
+// every lane of the wave holds the same value (one key point per wave): move it to a scalar register, so that what is derived from it
+// (tap bases, bounds) stays scalar too
+__device__ __forceinline__ unsigned int uniformU32(unsigned int v) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)v); }
+template <class T>
+__device__ __forceinline__ TapBases<T> makeBases(const T* d, int r, int stride, int W, int H) {
+	TapBases<T> B;
+	r = (int)uniformU32((unsigned)r);   // (the image base d is uniform already: kernel argument + uniform image index)
+	B.anyInside = (2 * r + 2 <= W) && (2 * r + 2 <= H);
+	// element distances; all zero when the image is smaller than the kernel (nothing may be read beyond element 0 then)
+	const long long st = B.anyInside ? stride : 0, rr = B.anyInside ? r : 0, w = B.anyInside ? 2 * r + 1 : 0;
+	const T* a = d;
+	const T* c1 = a + rr * st;
+	const T* c2 = c1 + st;
+	const T* b = c2 + rr * st;
+	B.a0 = (const char*)a; B.a1 = (const char*)(a + rr); B.a3 = (const char*)(a + w);
+	B.c10 = (const char*)c1; B.c13 = (const char*)(c1 + w);
+	B.c20 = (const char*)c2; B.c23 = (const char*)(c2 + w);
+	B.b0 = (const char*)b; B.b1 = (const char*)(b + rr); B.b3 = (const char*)(b + w);
+	B.r1 = (unsigned)(r + 1);
+	B.spanX = B.anyInside ? (unsigned)(W - 2 * r - 1) : 0u;
+	B.spanY = B.anyInside ? (unsigned)(H - 2 * r - 1) : 0u;
+	B.pitch4 = (unsigned)st * 4u;
+	return B;
+}
 template <class T>
 struct GradTaps {
 	T p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11;
 	bool inb;
 };
 template <class T>
-__device__ __forceinline__ void gradFetch(const T* __restrict__ d, const GradGeom& G, int x, int y, bool on, GradTaps<T>& t) {
-	const int r = G.r;
-	const bool inb = on && G.anyInside && x - r - 1 >= 0 && y - r - 1 >= 0 && x + r < G.W && y + r < G.H;
-	const int xs = inb ? x : G.safe, ys = inb ? y : G.safe;
-	// wave-uniform strides; all zero when the image is smaller than the kernel (nothing may be read beyond element 0 then)
-	const unsigned int st = G.anyInside ? (unsigned)G.stride : 0u, rr = G.anyInside ? (unsigned)r : 0u, w = G.anyInside ? (unsigned)G.w : 0u;
-	const unsigned int one = G.anyInside ? 1u : 0u;
-	// 32-bit element offsets from the (wave-uniform) image base: one integral image is far below 2^31 floats (W, H < 32768 is enforced
-	// by the detector, and the host rejects larger images for describe); unsigned, as the safe coordinates are never negative
-	const unsigned int s1 = (unsigned)(ys - r - 1) * st + (unsigned)(xs - r - 1) * one;
-	const unsigned int s2 = s1 + rr * st;
-	const unsigned int s3 = s2 + st;
-	const unsigned int s4 = s3 + rr * st;
-	t.p0 = d[s1]; t.p3 = d[s1 + w];
-	t.p11 = d[s2]; t.p4 = d[s2 + w];
-	t.p10 = d[s3]; t.p5 = d[s3 + w];
-	t.p9 = d[s4]; t.p6 = d[s4 + w];
-	if (G.anyInside) {
+__device__ __forceinline__ T tapAt(const char* base, unsigned int off) { return *(const T*)(base + off); }
+template <class T>
+__device__ __forceinline__ void gradFetch(const TapBases<T>& B, int x, int y, bool on, GradTaps<T>& t) {
+	// isInBounds (SparseScaleGradient.java:48-50): x-r-1 >= 0 && y-r-1 >= 0 && x+r < W && y+r < H, as two unsigned range tests
+	const unsigned int ux = (unsigned)x - B.r1, uy = (unsigned)y - B.r1;
+	const bool inb = on && ux < B.spanX && uy < B.spanY;
+	// 32-bit byte offset of the top-left tap from the image base: an integral image is below 2^32 bytes (checked on the host)
+	unsigned int off = inb ? __umul24(uy, B.pitch4) + ux * 4u : 0u;   // uy < 2^15, pitch4 < 2^19 when inb
+	// keep the offset a 32-bit register value of its own: the loads below are then "scalar base + zero-extended 32-bit lane offset", which
+	// is an addressing mode of global_load; if the compiler is left to fold the select into a 64-bit offset it adds base and offset per tap
+	// (buffer loads with the distances as scalar offsets measured 9 % slower than this form, with or without the sc0 policy)
+	asm volatile("" : "+v"(off));
+	t.p0 = tapAt<T>(B.a0, off); t.p3 = tapAt<T>(B.a3, off);
+	t.p11 = tapAt<T>(B.c10, off); t.p4 = tapAt<T>(B.c13, off);
+	t.p10 = tapAt<T>(B.c20, off); t.p5 = tapAt<T>(B.c23, off);
+	t.p9 = tapAt<T>(B.b0, off); t.p6 = tapAt<T>(B.b3, off);
+	if (B.anyInside) {
 		// the two centre columns of the top and of the bottom row are neighbours: one 8-byte request each instead of two 4-byte ones
 		// (the texture addresser is this kernel's co-limiter and works per lane access, not per byte)
-		const Pair2<T> a = *(const Pair2<T>*)(d + s1 + rr), b = *(const Pair2<T>*)(d + s4 + rr);
+		const Pair2<T> a = *(const Pair2<T>*)(B.a1 + off), b = *(const Pair2<T>*)(B.b1 + off);
 		t.p1 = a.x; t.p2 = a.y;
 		t.p8 = b.x; t.p7 = b.y;
 	} else {
-		t.p1 = d[s1 + rr]; t.p2 = d[s1 + rr + one];
-		t.p8 = d[s4 + rr]; t.p7 = d[s4 + rr + one];
+		t.p1 = t.p0; t.p2 = t.p0; t.p8 = t.p0; t.p7 = t.p0;
 	}
 	t.inb = inb;
 }
@@ -154,7 +181,8 @@ __device__ __forceinline__ void waveSync() {
 // and dX, dY are permuted into the same order.
 //
 // LDS layout of the orientation phase (n samples): while sorting  gX[n] gY[n] (fp32 gradients) | ang[n] (fp64) | 8n bytes of key
-// scratch | idxA[n] idxB[n] (u16) = 28n bytes; afterwards the same bytes hold dX[n] dY[n] sA[n] (fp64, sorted) | Esched[n] (int).
+// scratch | idxA[n] idxB[n] (u16) = 28n bytes; afterwards the same bytes hold dX[n] dY[n] sA[n] (fp64, sorted) | the window sweep's end-position
+// marks (256 * EPLT bytes from 24n on: they overlay the fp32 angle copies / bin offsets, which are dead by then).
 // The sorted fp64 samples are rebuilt as (double)g * weight[index] -- the expression the reference evaluates -- so only the
 // 4-byte gradients have to live through the sort.
 struct OriSortOut {
@@ -511,7 +539,7 @@ __device__ __forceinline__ bool countingSortScatter(const double (&a)[EPLT], con
 // The full-circle regime (some window wraps all the way round: ramps, flat patches) is detected and left to the serial code.
 // Returns false when the caller must run the serial sweep (the arrays are then still the sorted samples).
 template <int EPLT>
-__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, const float* sF, const unsigned int* bins, int* Esched, int n,
+__device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, const float* sF, const unsigned int* bins, unsigned int* marks, int n,
 												   double window, int lane, double& bestX, double& bestY, unsigned long long* st /*diagnostic stamps or nullptr*/) {
 #define WSTAMP(i) do { if (st && lane == 0) st[i] = __builtin_readcyclecounter(); } while (0)
 	const int EPL = (n + 63) >> 6;   // <= EPLT
@@ -588,19 +616,23 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 		}
 		// exact continuation, all of a lane's starts in lock step (their LDS reads overlap): the reference's own test walks on from the
 		// coarse count -- normally it fails at once; a handful of steps at most unless many samples sit within 1e-9 of the window edge
+		// One step = the reference's test `UtilAngle.dist(angle[start], angle[end]) <= windowSize` on the next successor, kept to the
+		// leading side.  With d1 = fl(next - start) (= -fl(start - next) exactly) and fo = d1, or fl(d1 + 2 pi) for a successor index that
+		// has wrapped past the end of the sorted list, UtilAngle.dist evaluates to fo whenever fo < pi, and the window is below pi (the
+		// caller checks < 3), so "leading side and inside" is exactly fo <= window.  A successor that fails it but lies within the window
+		// BEHIND the start -- dist = fl(2 pi - d1) unwrapped, -d1 wrapped -- would keep the reference's sweep going round the circle
+		// (UtilAngle.dist is symmetric): not a leading-side window, left to the serial sweep.
 		for (int guard = 0; guard < 18; guard++) {
 			bool any = false;
 #pragma unroll
 			for (int e = 0; e < EPLT; e++) {
 				if (act[e]) {
-					const int kabs = p0 + e + cc[e] + 1;
-					const double fo = (nxt[e] - ta[e]) + (kabs >= n ? 2.0 * M_PI : 0.0);
-					const bool inside = angleDist(ta[e], nxt[e]) <= window;
-					if (!(fo < M_PI && inside)) {
-						// UtilAngle.dist is symmetric: a successor that lies within the window BEHIND the start (the sweep has come round past
-						// +-pi, or past the end of the sorted list) still passes the reference's test and the reference keeps adding -- the window
-						// then runs on round the circle.  Not a leading-side window: leave it to the serial sweep.
-						if (inside) abnormal = true;
+					const bool wrapped = p0 + e + cc[e] + 1 >= n;
+					const double d1 = nxt[e] - ta[e];
+					const double fo = wrapped ? d1 + 2.0 * M_PI : d1;
+					if (!(fo <= window)) {
+						const double behind = wrapped ? -d1 : fabs(2.0 * M_PI + (-d1));
+						if (behind <= window) abnormal = true;
 						act[e] = false;
 					} else {
 						cc[e]++;
@@ -641,6 +673,7 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 	prevE = max(prevE, 1);
 	// ---- validate the schedule (full-circle regime -> serial code), before the samples are overwritten by their prefix sums
 	int lastE = 1;
+	int Ereg[EPLT];   // E(a) of this lane's starts
 	{
 		int pe = prevE;
 		double chk[EPLT];
@@ -649,6 +682,7 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 		for (int e = 0; e < EPLT; e++) {
 			need[e] = false;
 			chk[e] = 0.0;
+			Ereg[e] = 0;
 			if (e < cnt) {
 				const int a = p0 + e;
 				const int Ea = max(pe, valE[e]);
@@ -660,7 +694,7 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 				}
 				if (Ea >= a + n) abnormal = true;
 				pe = Ea;
-				Esched[a] = Ea;
+				Ereg[e] = Ea;
 			}
 		}
 #pragma unroll
@@ -704,29 +738,44 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 	double bMag = -1.0, bX = 0, bY = 0;
 	int bPos = 0x7fffffff;
 	if (lane == 0) { bX = dX[0]; bY = dY[0]; bMag = bX * bX + bY * bY; bPos = 0; }
-	// Owner of end position E: a(E) = min{a : Esched[a] > E} within [0, min(E, n-1)] (Esched[a] > a always, so the cap is a <= n-1).
-	// Walking E upwards while a follows is a merge of two sorted lists -- A = Esched[0..n-2], B = the end positions 1..lastE-1, A first on
-	// ties -- in which every B step is one candidate window (E, a).  Merge path deals the lenA + lenB steps out evenly: a lane finds its
-	// diagonal with one binary search and then takes S steps, so no lane is held up by a long run of owners.
+	// Owner of end position E: a(E) = min{a : E(a) > E} = #{a <= n-2 : E(a) <= E} (E(a) never decreases; E(a) > a always, so the owner
+	// is at most n-1).  Every start drops a mark at its E(a) (packed 16-bit counters, as in the counting sort), an inclusive scan over the
+	// end positions turns the marks into owners, and the candidate windows -- one per end position in [1, E(n-1)) -- are dealt out 64 at a
+	// time, each with four independent reads of the prefix sums.  `marks` has room for 2 * 64 * EPLT >= 2n end positions.
 	{
-		const int lenA = n - 1, lenB = lastE - 1;
-		const int tot = lenA + lenB;
-		const int S = (tot + 63) >> 6;
-		const int d = min(lane * S, tot);
-		int l0 = max(0, d - lenB), h0 = min(d, lenA);
-		for (int span = n; span > 0; span >>= 1) {
-			const bool on = l0 < h0;
-			const int mid = (l0 + h0) >> 1;
-			const int ev = on ? Esched[mid] : 0;
-			if (on) { if (ev <= d - mid) l0 = mid + 1; else h0 = mid; }   // B[d-1-mid] = d - mid
+#pragma unroll
+		for (int e = 0; e < EPLT; e++) marks[lane * EPLT + e] = 0u;
+		waveSync();
+#pragma unroll
+		for (int e = 0; e < EPLT; e++)
+			if (e < cnt && p0 + e <= n - 2) atomicAdd(&marks[Ereg[e] >> 1], 1u << ((Ereg[e] & 1) * 16));
+		waveSync();
+		{
+			unsigned int w[EPLT], pre[2 * EPLT];
+			unsigned int run = 0;
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) w[e] = marks[lane * EPLT + e];
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) {
+				run += w[e] & 0xffffu; pre[2 * e] = run;
+				run += w[e] >> 16; pre[2 * e + 1] = run;
+			}
+			unsigned int sc = run;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const unsigned int t = __shfl_up(sc, o, 64);
+				if (lane >= o) sc += t;
+			}
+			const unsigned int base = sc - run;
+#pragma unroll
+			for (int e = 0; e < EPLT; e++) marks[lane * EPLT + e] = (base + pre[2 * e]) | ((base + pre[2 * e + 1]) << 16);
 		}
-		int a = l0, j = d - l0;
-		int aKey = a < lenA ? Esched[a] : 0x7fffffff;
-		for (int st = 0; st < S; st++) {
-			const bool live = a + j < tot;
-			const int E = j + 1;
-			const bool takeA = aKey <= (j < lenB ? E : 0x7fffffff);
-			if (live && !takeA) {
+		waveSync();
+		const unsigned short* owner = (const unsigned short*)marks;
+		for (int E0 = 1; E0 < lastE; E0 += 64) {
+			const int E = E0 + lane;
+			if (E < lastE) {
+				const int a = owner[E];
 				const int ke = E >= n ? E - n : E;
 				const double ax = a > 0 ? dX[a - 1] : 0.0, ay = a > 0 ? dY[a - 1] : 0.0;
 				const double ex = dX[ke], ey = dY[ke];
@@ -736,8 +785,6 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 				const double mag = sx * sx + sy * sy;
 				if (mag > bMag) { bMag = mag; bX = sx; bY = sy; bPos = E; }   // E increases within a lane: strict > keeps the first
 			}
-			if (takeA) { a++; aKey = a < lenA ? Esched[a] : 0x7fffffff; }
-			else j++;
 		}
 	}
 	WSTAMP(11);
@@ -759,7 +806,11 @@ __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const 
 
 // STAMP = true is a diagnostic build (BHIP_DESCRIBE_STAMPS): lane 0 of every wave records the cycle counter at the phase boundaries
 // into a buffer nothing else reads; never used for results or for quoted run times.
+#ifdef BHIP_EXPERIMENTS
+#define DSTAMP(i) do { if (STAMP && lane == 0) P.stamps[g * 16 + (i)] = __builtin_readcyclecounter(); if (P.stopAfter == (i)) return; } while (0)
+#else
 #define DSTAMP(i) do { if (STAMP && lane == 0) P.stamps[g * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#endif
 
 // EPLT = orientation samples per lane = ceil(n / 64), TWT = samples per sub-region row: compile-time for the common configurations so
 // the unrolled batches carry no dead slots (the kernel is issue bound); <8,16> is the generic instantiation.
@@ -798,6 +849,8 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		img = P.singleImage;
 		local = (int)g;
 	}
+	img = (int)uniformU32((unsigned)img);
+	local = (int)uniformU32((unsigned)local);
 	const KeyPoint kp = P.imageStart ? P.kps[(long long)img * P.cap + local] : P.kps[local];
 	const TAP* __restrict__ d = (const TAP*)P.ii.data + (long long)img * P.ii.imageStride;
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
@@ -806,12 +859,13 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	DSTAMP(0);
 	// ------------------------------------------------------------------ orientation
 	double angle;
+	double dirX = 0.0, dirY = 0.0;   // the vector whose atan2 is the orientation (when it is computed here)
 	if (P.anglesIn) {
 		angle = P.anglesIn[g];
 	} else {
 		const double radius = kp.scale * P.oriRadiusFactor;
 		const double oscale = radius * T.oriRadiusToScale;    // setObjectRadius
-		const GradGeom G = makeGeom(gradRadius(oscale * T.oriKernelWidth), stride, W, H);
+		const TapBases<TAP> G = makeBases<TAP>(d, gradRadius(oscale * T.oriKernelWidth), stride, W, H);
 		const double period = oscale * T.oriPeriod;
 		double tl_x = kp.x - T.oriRadius * period;
 		double tl_y = kp.y - T.oriRadius * period;
@@ -838,7 +892,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				const int sy = idx / sw, sx = idx - sy * sw;
 				const int xx = (int)(tl_x + sx * period);
 				const int yy = (int)(tl_y + sy * period);
-				gradFetch<TAP>(d, G, xx, yy, idx < n, tp[e]);
+				gradFetch<TAP>(G, xx, yy, idx < n, tp[e]);
 			}
 #pragma unroll
 			for (int e = 0; e < EPLT; e++) gradFinish<TAP>(tp[e], gx[e], gy[e]);
@@ -896,7 +950,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			}
 			ang = so.sA;   // sorted angles; dX, dY hold the sorted samples
 			DSTAMP(2);
-			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, counted ? bins : nullptr, (int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
+			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, counted ? bins : nullptr, (unsigned int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
 			if (needSerial) {
 				// estimateAngle() exactly as written in the reference, on the arrays already in sorted order (order[k] == k).
 				// Reached for the full-circle regime (all gradients within one window of each other: ramps, flat patches).
@@ -930,6 +984,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				bestY = __shfl(bestY, 0, 64);
 			}
 			angle = atan2(bestY, bestX);
+			dirX = bestX; dirY = bestY;
 		} else {
 			double Dx = 0, Dy = 0;
 			if (lane == 0) {
@@ -938,6 +993,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			Dx = __shfl(Dx, 0, 64);
 			Dy = __shfl(Dy, 0, 64);
 			angle = atan2(Dy, Dx);
+			dirX = Dx; dirY = Dy;
 		}
 		waveSync();
 	}
@@ -946,9 +1002,21 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	if (!P.desc) return;
 
 	// ------------------------------------------------------------------ descriptor
-	const double c = cos(angle), s = sin(angle);
+	// c = cos(angle), s = sin(angle) (DescribePointSurf.describe :190-191).  When the angle was formed here as atan2(dirY, dirX), the unit
+	// vector dir / |dir| is cos / sin of the exact angle to within 2 ulp -- as close to the reference's cos(fl(atan2)) as two libm's are to
+	// each other ("last ulp of Math.sin/cos/atan2") -- for a tenth of the instructions of an fp64 sincos.
+	double c, s;
+	{
+		const double h2 = dirX * dirX + dirY * dirY;
+		if (h2 > 1.0e-200 && h2 < 1.0e200) {   // wave-uniform; false for a caller-supplied angle (dir = 0)
+			const double h = sqrt(h2);
+			c = dirX / h; s = dirY / h;
+		} else {
+			c = cos(angle); s = sin(angle);
+		}
+	}
 	const double scale = kp.scale;
-	const GradGeom G = makeGeom(gradRadius(T.widthSample * scale), stride, W, H);
+	const int descR = gradRadius(T.widthSample * scale);
 	const int widthLargeGrid = CFG ? 4 : T.widthLargeGrid, widthSubRegion = CFG ? 5 : T.widthSubRegion;
 	const bool stableDesc = CFG == 1 ? true : CFG == 2 ? false : (T.stable != 0);
 	const int regionSize = widthLargeGrid * widthSubRegion;
@@ -986,6 +1054,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	for (int band = 0; band < nb; band++) {
 	const TAP* __restrict__ db = P.nBands > 0 ? (const TAP*)P.bandData + (long long)img * P.bandImageStride + (long long)band * P.bandStride : d;
 	if (band > 0) waveSync();   // the previous band's sums have read sX, sY
+	const TapBases<TAP> G = makeBases<TAP>(db, descR, stride, W, H);
 	{
 		// sample grid in 8x8 blocks: the 64 lanes of one pass cover a compact (8 scale)^2 patch of the image, so a wave-level gather
 		// touches a few dozen cache lines instead of up to 64.  The LDS layout stays [iy][ix].
@@ -993,6 +1062,42 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 		const int blocksPerSide = (gridW + 7) >> 3;
 		const int nblocks = blocksPerSide * blocksPerSide;
 		const int ly = lane >> 3, lx = lane & 7;
+		const int gridOff = regionR + overLap;
+		if (CFG != 0) {
+			// default grids (24 or 20 samples per side) are three blocks per side: one batch = one row of blocks.  The products of the
+			// reference's expressions  pixelX = (int)(c_x + c*regionX - s*regionY),  pixelY = (int)(c_y + s*regionX + c*regionY)
+			// (DescribePointSurfMod.java:144-150, DescribePointSurf.java:256-262; evaluated left to right) depend on the sample's column only
+			// (first two terms) or row only (last term), so they are formed once per lane and block column / block row -- same values,
+			// same roundings, a third of the fp64 instructions.
+			static_assert(DESC_BATCH == 3, "one batch = one row of three blocks");
+			double PX[3], PY[3];
+#pragma unroll
+			for (int u = 0; u < 3; u++) {
+				const int rX = 8 * u + lx - gridOff;
+				const double regionX = rX * scale;
+				PX[u] = c_x + c * regionX;
+				PY[u] = c_y + s * regionX;
+			}
+#pragma unroll 1
+			for (int by = 0; by < 3; by++) {
+				GradTaps<TAP> tp[3];
+				const int iy = 8 * by + ly;
+				const double regionY = (iy - gridOff) * scale;
+				const double qx = s * regionY, qy = c * regionY;
+#pragma unroll
+				for (int u = 0; u < 3; u++) {
+					const bool on = iy < gridW && 8 * u + lx < gridW;
+					gradFetch<TAP>(G, (int)(PX[u] - qx), (int)(PY[u] + qy), on, tp[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < 3; u++) {
+					TAP gx, gy;
+					gradFinish<TAP>(tp[u], gx, gy);
+					const int ix = 8 * u + lx;
+					if (iy < gridW && ix < gridW) { sX[iy * gridW + ix] = (double)gx; sY[iy * gridW + ix] = (double)gy; }
+				}
+			}
+		} else {
 #pragma unroll 1
 		for (int b0 = 0; b0 < nblocks; b0 += DESC_BATCH) {
 			GradTaps<TAP> tp[DESC_BATCH];
@@ -1004,12 +1109,12 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				const int iy = 8 * by + ly, ix = 8 * bx + lx;
 				const bool on = b < nblocks && iy < gridW && ix < gridW;
 				at[u] = on ? iy * gridW + ix : -1;
-				const int rY = iy - regionR - overLap, rX = ix - regionR - overLap;
+				const int rY = iy - gridOff, rX = ix - gridOff;
 				const double regionY = rY * scale;
 				const double regionX = rX * scale;
 				const int pixelX = (int)(c_x + c * regionX - s * regionY);
 				const int pixelY = (int)(c_y + s * regionX + c * regionY);
-				gradFetch<TAP>(db, G, pixelX, pixelY, on, tp[u]);
+				gradFetch<TAP>(G, pixelX, pixelY, on, tp[u]);
 			}
 #pragma unroll
 			for (int u = 0; u < DESC_BATCH; u++) {
@@ -1017,6 +1122,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 				gradFinish<TAP>(tp[u], gx, gy);
 				if (at[u] >= 0) { sX[at[u]] = (double)gx; sY[at[u]] = (double)gy; }
 			}
+		}
 		}
 	}
 	waveSync();
@@ -1158,12 +1264,15 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	P.stamps = nullptr;
 	P.serialOnly = bhip_env_flag("BHIP_DESCRIBE_SERIAL") ? 1 : 0;   // parity cross-checks of the two window sweeps / the two sort keys
 	P.sort64 = bhip_env_flag("BHIP_DESCRIBE_SORT64") ? 1 : 0;
+#ifdef BHIP_EXPERIMENTS
+	{ const char* e = getenv("BHIP_DESCRIBE_STOP"); P.stopAfter = e ? atoi(e) : -1; }
+#endif
 	if (t.oriWidth * t.oriWidth > 64 * ORI_EPL_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation sample grid too large for the GPU path");
 	if (t.widthSubRegion + 2 * (t.stable ? t.overLap : 0) > DESC_ROW_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "SURF sub-region too wide for the GPU path");
 	if (P.ldsPerWave * 4 > 160 * 1024) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation/descriptor sample grid too large for LDS");
 	const long long blocks = ((((total + 3) / 4) + 7) / 8) * 8;   // whole rounds over the 8 XCDs
 	if (blocks > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_INVALID, "too many key points");
-	if ((long long)ii.stride * ii.height > 0x7fffffffLL) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "integral image too large for 32-bit tap offsets");
+	if ((long long)ii.stride * ii.height > 0x3fffffffLL || ii.stride >= (1 << 17)) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "integral image too large for 32-bit tap offsets");
 #ifdef BHIP_EXPERIMENTS
 	const char* stampPath = getenv("BHIP_DESCRIBE_STAMPS");
 	if (stampPath && total > 1000 && !(planar && planar->intTaps)) {
@@ -1231,6 +1340,22 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 		// colour SURF with many bands / large sample grids need more than the default 64 KB of dynamic LDS
 		if (ldsBytes > 65536) BHIP_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
 		void* args[] = {(void*)&P};
+#ifdef BHIP_EXPERIMENTS
+		{
+			// experiment: orientation and descriptor as two launches of the same kernel (how long does each half take on its own?)
+			const char* e = getenv("BHIP_DESCRIBE_SPLIT");
+			if (e && e[0] == '1' && P.angles && P.desc && !P.anglesIn) {
+				DescParams Po = P, Pd = P;
+				Po.desc = nullptr; Po.white = nullptr;
+				Pd.anglesIn = P.angles;
+				void* ao[] = {(void*)&Po};
+				void* ad[] = {(void*)&Pd};
+				{ ProfScope p1(ctx, "k_describe_ori"); BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, ao, ldsBytes, ctx->stream)); }
+				{ ProfScope p2(ctx, "k_describe_desc"); BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, ad, ldsBytes, ctx->stream)); }
+				return BHIP_OK;
+			}
+		}
+#endif
 		BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, args, ldsBytes, ctx->stream));
 	}
 	BHIP_HIP(ctx, hipGetLastError());

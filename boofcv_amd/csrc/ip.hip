@@ -994,9 +994,11 @@ struct BriefParams {
 	int stride, width, height, radius, numPoints, words, n;
 	const int* samplePoints;  // [numPoints][2]
 	const int* compare;       // [numPoints][2]
-	const double* xy;         // [n][2]
+	const double* xy;         // [n][xyStride] compact, or [image][xyImageStride] records when xyImageStride != 0; (x, y) first
 	int* out;                 // [n][words]
 	const int* start;         // batched: points of image b are [start[b], start[b+1]); nullptr: one image, n points
+	int xyStride;             // doubles between consecutive points (2 for (x,y) pairs, 4 for KeyPoint records)
+	long long xyImageStride;  // doubles between the point lists of consecutive images (0: one compact list indexed by start[])
 };
 
 // one thread = one 32-pair word of one key point.  PIX = float (ImplDescribeBinaryCompare_F32: a pair outside the image is skipped
@@ -1009,7 +1011,8 @@ __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 	if (t >= (long long)count * P.words) return;
 	const int pl = (int)(t / P.words), word = (int)(t - (long long)pl * P.words);
 	const int p = first + pl;
-	const int c_x = (int)P.xy[2 * p], c_y = (int)P.xy[2 * p + 1];
+	const double* pt = P.xyImageStride ? P.xy + (long long)blockIdx.y * P.xyImageStride + (long long)pl * P.xyStride : P.xy + (long long)p * P.xyStride;
+	const int c_x = (int)pt[0], c_y = (int)pt[1];
 	const bool inside = !(c_x - P.radius < 0 || c_x + P.radius >= P.width || c_y - P.radius < 0 || c_y + P.radius >= P.height);
 	const int i0 = word * 32, i1 = min(P.numPoints, i0 + 32);
 	const PIX* img = (const PIX*)P.img + (long long)blockIdx.y * P.imageStride;
@@ -1033,9 +1036,10 @@ __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 
 // start == nullptr: n points on one image.  Otherwise `batch` images and device prefix `start` (batch+1); maxCount = largest per-image count.
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
-					  const int* compare, const double* xy, int n, int* out, bool u8, int batch, long long imageStride, const int* start, int maxCount) {
+					  const int* compare, const double* xy, int n, int* out, bool u8, int batch, long long imageStride, const int* start, int maxCount,
+					  int xyStride, long long xyImageStride) {
 	if (n <= 0) return BHIP_OK;
-	BriefParams P{img, imageStride, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out, start};
+	BriefParams P{img, imageStride, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out, start, xyStride, xyImageStride};
 	const long long total = (long long)(start ? maxCount : n) * P.words;
 	if (total <= 0) return BHIP_OK;
 	dim3 grid((unsigned)((total + 255) / 256), start ? batch : 1);

@@ -138,6 +138,28 @@ int bhip_surf_fetch_all(bhip_surf* s, double* xy_scale, double* angle, uint8_t* 
  * descriptor upload.  pairs / fit: host arrays of bhip_surf_total entries; problem p's results start at the exclusive prefix of the counts
  * of srcImage[p] (an image may be the source of one problem per call); entries of images that are no source read -1 / 0.0. */
 int bhip_assoc_l2_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit);
+
+/* ---- Fast-Hessian + BRIEF as one DetectDescribePoint<T,TupleDesc_B>:
+ *      FactoryDetectDescribe.fuseTogether(FactoryInterestPoint.fastHessian(fh), null, FactoryDescribeRegionPoint.brief(config, imageType))
+ *      (F:factory/feature/detdesc/FactoryDetectDescribe.java:279-284; F:abst/feature/detdesc/DetectDescribeFusion.java:95-127;
+ *       F:abst/feature/detect/interest/WrapFHtoInterestPoint.java:47-79; F:factory/feature/describe/FactoryDescribeRegionPoint.java:187-202;
+ *       F:abst/feature/describe/WrapDescribeBrief.java:47-58; F:alg/feature/describe/DescribePointBrief.java:71-89), config.fixed = true.
+ *      The definition (radius, numPoints, samplePoints, compare: FactoryBriefDefinition.gaussian2(new Random(123), radius, numPoints)) is
+ *      generated on the Java side, as for bhip_brief_f32.  The object is a bhip_surf: detect with bhip_surf_detect_f32 / _dev_f32 / _u8 (GrayU8
+ *      frames: GrayS32 integral image + ImplDescribeBinaryCompare_U8), read locations with bhip_surf_count / _total / _fetch (desc = NULL;
+ *      getOrientation(i) is 0, getRadius(i) = scale*2), destroy with bhip_surf_destroy.  Every detected point is described (process() of the
+ *      fixed BRIEF always returns true), in detector order; the words are taken from the frame itself (the reference blurs a copy it never
+ *      reads), with the border rule of the image type (see bhip_brief_f32 / bhip_brief_u8). ---- */
+int bhip_surf_create_brief(bhip_ctx* ctx, const bhip_fh_cfg* fh, int radius, int numPoints, const int32_t* samplePoints, const int32_t* compare,
+						   bhip_surf** out);
+/* getDescription(i).data (TupleDesc_B: ceil(numPoints/32) ints per feature, T:struct/feature/TupleDesc_B.java) of every feature of image
+ * `image` of the last detect, or of the whole batch when image = -1 (image i's slice then starts at the exclusive prefix of the counts) */
+int bhip_surf_fetch_brief(bhip_surf* s, int image, int32_t* words);
+/* device view of the same words (valid until the next detect on s); *words = ints per feature */
+int bhip_surf_dev_view_brief(bhip_surf* s, int image, const int32_t** dev_words, int* words, int* n);
+/* AssociateDescription<TupleDesc_B>.associate() with ScoreAssociateHamming_B (F:alg/descriptor/DescriptorDistance.java:196-220) on the words still
+ * resident from the last detect of a BRIEF object: contract of bhip_assoc_l2_surf, rules and results of bhip_assoc_hamming, no upload */
+int bhip_assoc_hamming_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit);
 /* device views of the same results (valid until the next detect): descriptors [n][dof] doubles, laplacian signs [n] bytes */
 int bhip_surf_dev_view(bhip_surf* s, int image, const double** dev_desc, const double** dev_xy_scale, const uint8_t** dev_white, int* n);
 int bhip_surf_dof(bhip_surf* s);

@@ -21,6 +21,17 @@ __device__ __forceinline__ unsigned hashu(unsigned x) {
 // MODE 2: orientation pattern (axis aligned, lane = sample index), 10 accesses
 // MODE 3: descriptor pattern from LDS (random ds_read_b32 in a per-wave region), 12 reads
 // MODE 4: descriptor pattern, 1 access per sample (p0 only) -- per-instruction cost without same-line reuse between taps
+// cache-policy variants of a 4-byte global load (MODE 5: nt, 6: sc0 sc1, 7: sc1, 8: sc0)
+template <int POL>
+__device__ __forceinline__ float loadPol(const float* p) {
+	float v;
+	if (POL == 5) asm volatile("global_load_dword %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+	else if (POL == 6) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+	else if (POL == 7) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+	else asm volatile("global_load_dword %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+	return v;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ img, int W, int H, int pitch, long long imgStride, int nImg, float s, int kpPerWave,
 												 float* __restrict__ out) {
@@ -83,6 +94,17 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ img, i
 				const unsigned s2 = s1 + r * pitch, s3 = s2 + pitch, s4 = s3 + r * pitch;
 				const unsigned w = 2 * r + 1;
 				if (MODE == 4) { acc += d[s1]; continue; }
+				if (MODE >= 5) {
+					// the twelve taps as 4-byte loads with a cache policy; waited for once per sample block
+					float t[12];
+					const unsigned o[12] = {s1, s1 + r, s1 + r + 1, s1 + w, s2, s2 + w, s3, s3 + w, s4, s4 + r, s4 + r + 1, s4 + w};
+#pragma unroll
+					for (int q = 0; q < 12; q++) t[q] = loadPol<MODE>(d + o[q]);
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+					for (int q = 0; q < 12; q++) acc += t[q];
+					continue;
+				}
 				const float p0 = d[s1], p3 = d[s1 + w], p11 = d[s2], p4 = d[s2 + w], p10 = d[s3], p5 = d[s3 + w], p9 = d[s4], p6 = d[s4 + w];
 				float p1, p2, p8, p7;
 				if (MODE == 0) {
@@ -128,6 +150,16 @@ int main(int argc, char** argv) {
 	const double clk = 2.4e9, cus = 256;
 	printf("key points per launch %.0f; CU-cycles per key point = ms * 1e-3 * 2.4e9 * 256 / kps\n", kps);
 	const float scales[] = {2.f, 3.f, 4.f, 5.4f, 8.f, 12.f, 18.f};
+	printf("cache policies, 12 x 4-byte taps per sample, 40 KB LDS per workgroup: ms per launch\n%6s %10s %10s %10s %10s %10s\n", "scale", "default", "nt", "sc0 sc1", "sc1", "sc0");
+	for (float s : scales) {
+		const double a = run<1>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, 40960, out);
+		const double b5 = run<5>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, 40960, out);
+		const double b6 = run<6>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, 40960, out);
+		const double b7 = run<7>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, 40960, out);
+		const double b8 = run<8>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, 40960, out);
+		printf("%6.1f %10.3f %10.3f %10.3f %10.3f %10.3f\n", s, a, b5, b6, b7, b8);
+	}
+	if (argc > 1) return 0;
 	const size_t ldsOpts[] = {40960, 20480, 10240};
 	for (size_t lb : ldsOpts) {
 		printf("--- dynamic LDS per workgroup %zu B (%d workgroups / CU by LDS)\n", lb, (int)(163840 / lb));
