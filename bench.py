@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16: what k_assoc_mfma_* issue)
 INT8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (spec); the exact-fp64 association path is VALU, not MFMA
 PCIE_GBS = 63.0  # MI355X_MICROARCH.md: host link PCIe Gen5 x16 (spec)
@@ -51,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as fill %.0f s, at least 3)" % MIN_TIMED_SECONDS)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["frames", "assoc_sharded", "chain4k"], default="frames")
+    ap.add_argument("--workload", choices=["frames", "assoc_sharded", "chain4k", "brief_frames"], default="frames")
     ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (frames: 256 = BASELINE config; chain4k: 8)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
@@ -516,7 +517,8 @@ def run_frames(args, D):
                         "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"])}
         else:
             achieved = (r["flops"] / r["launches"] / per_launch_s / 1e12) if r["flops"] > 0 else 0.0
-            peak = FP32_MFMA_PEAK_TFLOPS if "mfma" in tag else FP64_VECTOR_PEAK_TFLOPS
+            # the association's matrix-core passes run v_mfma_f32_32x32x16_f16 (fp16 candidate filter); everything else with flops is fp64 VALU
+            peak = FP16_MFMA_PEAK_TFLOPS if tag.startswith("k_assoc_mfma") else FP32_MFMA_PEAK_TFLOPS if "mfma" in tag else FP64_VECTOR_PEAK_TFLOPS
             roofline = {"kernel": tag, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4), "traffic": None,
                         "avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"]}
@@ -547,7 +549,8 @@ def run_frames(args, D):
     return {
         "metric": "1080p frames/sec detect+describe+associate", "value": round(value, 2), "unit": "frames/s", "n_gpus": D.world,
         "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32 detect / f64 describe+associate", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 detect / f64 describe / associate: fp16 MFMA candidate filter + exact fp64 re-score", "data": "synthetic",
         "config": {"workload": "batch of %d %dx%d GrayF32 per GPU: Fast-Hessian detect + SURF-64 (stable) describe + greedy L2 associate with the next frame"
                                % (B, W, H), "batch_per_gpu": B, "width": W, "height": H, "keypoints_per_frame": round(kp_all / (D.world * B), 1),
                    "ranks_seen": D.ranks_seen()},
@@ -700,6 +703,84 @@ def run_chain4k(args, D):
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------- workload: brief_frames
+def run_brief_frames(args, D):
+    """Fast-Hessian + BRIEF-512 (DetectDescribeFusion(fastHessian, null, brief)) on a device-resident batch, then greedy Hamming
+    association of every frame with the next one on the words still resident: the BRIEF form of the default workload."""
+    import ctypes as C
+    import numpy as np
+    torch = D.torch
+    from boofcv_amd import api, _lib
+    L = _lib.load()
+    B = args.batch or 256
+    H = args.height or 1080
+    W = args.width or 1920
+    frames = synth_frames(B, H, W, 1000 + D.rank * B, D.device)
+    ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream(D.local_rank).cuda_stream)
+    brief = api.FactoryDescribeRegionPoint.brief(None, api.GrayF32, ctx=ctx)
+    dd = api.FactoryDetectDescribe.fuseTogether(api.FactoryInterestPoint.fastHessian(None), None, brief, ctx=ctx)
+    out = {"pairs": None, "fit": None, "total": 0}
+    LL, I = C.POINTER(C.c_longlong), C.POINTER(C.c_int)
+
+    def step():
+        dd.detectDevice(frames.data_ptr(), H * W, W, W, H, B)
+        total = dd.totalFeatures()
+        if out["pairs"] is None or out["pairs"].numel() < total:
+            out["pairs"] = torch.empty(max(total, 1) * 2, dtype=torch.int32, device=frames.device)
+            out["fit"] = torch.empty(max(total, 1) * 2, dtype=torch.float64, device=frames.device)
+        views = [dd.deviceViewBrief(i) for i in range(B)]
+        counts = np.array([v[2] for v in views], dtype=np.int32)
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        base = views[0][0]
+        dst_idx = (np.arange(B) + 1) % B
+        so, do_ = np.ascontiguousarray(starts[:B]), np.ascontiguousarray(starts[dst_idx])
+        ns, nd = np.ascontiguousarray(counts), np.ascontiguousarray(counts[dst_idx])
+        st = L.bhip_assoc_hamming_dev_batched(ctx._h, C.c_void_p(base), C.c_void_p(base), 16, B, so.ctypes.data_as(LL), ns.ctypes.data_as(I), do_.ctypes.data_as(LL),
+                                              nd.ctypes.data_as(I), api.Double_MAX_VALUE, 1, C.c_void_p(out["pairs"].data_ptr()), C.c_void_p(out["fit"].data_ptr()))
+        if st != 0:
+            raise RuntimeError("bhip_assoc_hamming_dev_batched failed: %s" % L.bhip_last_error(ctx._h))
+        out["total"] = total
+        return total
+
+    for _ in range(max(args.warmup, 0)):
+        step()
+    warm = args.warmup
+    args.warmup = 0
+    ctx.profile(True); ctx.profileReset()
+    if args.steps is None:
+        D.barrier()
+        t0 = time.perf_counter(); step(); torch.cuda.synchronize()
+        one = D.max(time.perf_counter() - t0)
+        args.steps = int(D.max(float(max(3, int(MIN_TIMED_SECONDS / max(one, 1e-6)) + 1))))
+        ctx.profileReset()
+    steps, elapsed, _ = timed_steps(D, args, step)
+    args.warmup = warm
+    prof = ctx.profileReport(); ctx.profile(False)
+    kp_all = D.sum(float(out["total"]))
+    matched = D.sum(float((out["pairs"][:out["total"]] >= 0).sum().item()))
+    if D.rank != 0:
+        return None
+    tag, r = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_s = r["ms"] / r["launches"] / 1e3
+    if r["bytes"] > 0:
+        achieved = r["bytes"] / r["launches"] / per_launch_s / 1e9
+        roofline = {"kernel": tag, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+    else:
+        tops = r["flops"] / r["launches"] / per_launch_s / 1e12 if r["flops"] > 0 else 0.0
+        roofline = {"kernel": tag, "bound": "valu", "achieved": round(tops, 2), "peak": None, "unit": "T popcount-ops/s", "frac": None, "traffic": None}
+    roofline.update({"avg_launch_ms": round(r["ms"] / r["launches"], 4), "launches": r["launches"],
+                     "kernels_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}})
+    return {
+        "metric": "1080p frames/sec Fast-Hessian detect + BRIEF-512 describe + Hamming associate", "value": round(D.world * B * steps / elapsed, 2), "unit": "frames/s",
+        "n_gpus": D.world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 detect / u32 words, popcount Hamming", "data": "synthetic",
+        "config": {"workload": "batch of %d %dx%d GrayF32 per GPU, device resident: Fast-Hessian + BRIEF-512 (fuseTogether(fastHessian, null, brief)) + greedy Hamming "
+                               "associate with the next frame on the resident words" % (B, W, H), "batch_per_gpu": B, "width": W, "height": H,
+                   "keypoints_per_frame": round(kp_all / (D.world * B), 1), "matches_per_frame": round(matched / (D.world * B), 1), "ranks_seen": D.ranks_seen()},
+        "roofline": roofline, "cpu_baseline": None,
+    }
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -720,7 +801,7 @@ def main():
         (sys.stdout if rank == 0 else sys.stderr).write(json.dumps(line) + "\n")
         return
     D = Dist(args)
-    line = {"frames": run_frames, "assoc_sharded": run_assoc_sharded, "chain4k": run_chain4k}[args.workload](args, D)
+    line = {"frames": run_frames, "assoc_sharded": run_assoc_sharded, "chain4k": run_chain4k, "brief_frames": run_brief_frames}[args.workload](args, D)
     if D.rank == 0:
         assert line["n_gpus"] == args.gpus
         if D.rehearsal:

@@ -80,6 +80,7 @@ SIGNATURES = {
     "bhip_assoc_l2_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _i, _i, _vp, _vp]),
     "bhip_assoc_hamming_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _i, _vp, _vp]),
     "bhip_assoc_l2_dev_batched": (_i, [_vp, _vp, _vp, _i, _i, _llp, _ip, _llp, _ip, _d, _i, _vp, _vp]),
+    "bhip_assoc_hamming_dev_batched": (_i, [_vp, _vp, _vp, _i, _i, _llp, _ip, _llp, _ip, _d, _i, _vp, _vp]),
     "bhip_assoc_l2_shard_phase1": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _d, _vp, _vp, _vp]),
     "bhip_assoc_hamming_shard_phase1": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _d, _vp, _vp, _vp]),
     "bhip_assoc_shard_phase2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

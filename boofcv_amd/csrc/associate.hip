@@ -14,6 +14,8 @@
 // problem writes (min1, min2, argmin1) records that are all-gathered across ranks and merged by k_assoc_finish.
 #include "common.h"
 #include <cfloat>
+#include <cmath>
+#include <algorithm>
 
 struct ColTop {
 	double min1, min2;
@@ -309,6 +311,136 @@ static int phase2(bhip_ctx* ctx, const ColTop* colAll, int nranks, int nd, int n
 	if (nsLocal <= 0 || nd <= 0) return BHIP_OK;
 	hipLaunchKernelGGL(k_assoc_finish, dim3((nsLocal + 255) / 256), dim3(256), 0, ctx->stream, colAll, nranks, nd, nsLocal, srcBegin, pairs, fit);
 	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched Hamming association: many small independent problems (frame i against frame i+1 of a batch of BRIEF word lists) in three
+// launches.  A problem of ~2000 x 2000 x 512 bits is far too small to fill the chip on its own (and the int8 matrix-core path pays a byte
+// expansion per call), so here one thread owns a word list of U in registers and scans every word list of V through an LDS tile with
+// xor + popcount: exact integer scores, the reference's rules applied directly --
+//   rows   : minimum score, LARGEST destination index among equal minima (`fit <= best`), inclusive maxFitError
+//   columns: (min1, argmin1, min2) over the sources; (i -> m) survives iff i is the arg-min of column m and min2 > min1.
+// Bound: VALU popcount, 2 ops per word and pair: Ns * Nd * words * 2 per pass.
+struct HamProb {
+	long long srcOff, dstOff, colOff;   // rows into the source / destination word arrays; first column record of this problem
+	int ns, nd;
+};
+struct HamCol { int min1, min2, idx1; };
+
+template <int WORDS, bool COLMODE>
+__global__ __launch_bounds__(256) void k_ham_batched(const int* __restrict__ S, const int* __restrict__ D, const HamProb* __restrict__ probs, int words, int thr,
+													  double maxErr, int* __restrict__ pairs, double* __restrict__ fit, HamCol* __restrict__ col) {
+	__shared__ int tile[VT * (WORDS > 0 ? WORDS : 64)];
+	const HamProb pr = probs[blockIdx.y];
+	const int W = WORDS > 0 ? WORDS : words;
+	const int nU = COLMODE ? pr.nd : pr.ns, nV = COLMODE ? pr.ns : pr.nd;
+	if ((int)(blockIdx.x * blockDim.x) >= nU) return;   // whole block: uniform
+	const int* __restrict__ U = COLMODE ? D + pr.dstOff * W : S + pr.srcOff * W;
+	const int* __restrict__ V = COLMODE ? S + pr.srcOff * W : D + pr.dstOff * W;
+	const int ui = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool active = ui < nU;
+	int a[WORDS > 0 ? WORDS : 1];
+	const int* urow = U + (long long)(active ? ui : 0) * W;
+	if (WORDS > 0) {
+#pragma unroll
+		for (int k = 0; k < WORDS; k++) a[k] = urow[k];
+	}
+	int best = thr, bestIdx = -1;                 // rows: running bound starts at floor(maxFitError)
+	int min1 = 0x7fffffff, min2 = 0x7fffffff;     // columns
+	for (int t0 = 0; t0 < nV; t0 += VT) {
+		const int nt = min(VT, nV - t0);
+		__syncthreads();
+		for (int e = threadIdx.x; e < nt * W; e += blockDim.x) tile[e] = V[(long long)t0 * W + e];
+		__syncthreads();
+		if (active) {
+			for (int j = 0; j < nt; j++) {
+				int sc = 0;
+				if (WORDS > 0) {
+#pragma unroll
+					for (int k = 0; k < WORDS; k++) sc += __popc((unsigned)(a[k] ^ tile[j * WORDS + k]));
+				} else {
+					for (int k = 0; k < W; k++) sc += __popc((unsigned)(urow[k] ^ tile[j * W + k]));
+				}
+				if (!COLMODE) {
+					if (sc <= best) { best = sc; bestIdx = t0 + j; }
+				} else {
+					if (sc < min1) { min2 = min1; min1 = sc; bestIdx = t0 + j; }
+					else if (sc < min2) { min2 = sc; }
+				}
+			}
+		}
+	}
+	if (!active) return;
+	if (!COLMODE) {
+		pairs[pr.srcOff + ui] = bestIdx;
+		fit[pr.srcOff + ui] = bestIdx >= 0 ? (double)best : maxErr;
+	} else {
+		HamCol c; c.min1 = min1; c.min2 = min2; c.idx1 = bestIdx;
+		col[pr.colOff + ui] = c;
+	}
+}
+__global__ __launch_bounds__(256) void k_ham_batched_finish(const HamProb* __restrict__ probs, const HamCol* __restrict__ col, int* __restrict__ pairs,
+															 double* __restrict__ fit) {
+	const HamProb pr = probs[blockIdx.y];
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= pr.ns) return;
+	const int m = pairs[pr.srcOff + i];
+	if (m < 0) return;
+	const HamCol c = col[pr.colOff + m];
+	if (!(c.idx1 == i && c.min2 > c.min1)) {
+		pairs[pr.srcOff + i] = -1;
+		fit[pr.srcOff + i] = DBL_MAX;
+	}
+}
+
+// problems: host table (count entries; colOff filled in here).  work: scratch for the table and the column records.
+int bhip_assoc_hamming_batched(bhip_ctx* ctx, const int32_t* src, const int32_t* dst, int words, int count, const long long* srcOff, const int* ns,
+							   const long long* dstOff, const int* nd, double maxErr, int backwards, int* pairs, double* fit, DevBuf& work) {
+	if (count <= 0) return BHIP_OK;
+	if (words <= 0 || words > 64) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "BRIEF descriptor too long for the batched Hamming kernel");
+	if ((size_t)count * sizeof(HamProb) > (1u << 20)) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "too many problems in one batched call");
+	HamProb* hp = (HamProb*)ctx->hostScratch;   // pinned: the copy below is asynchronous
+	long long cols = 0;
+	int maxNs = 0, maxNd = 0;
+	for (int p = 0; p < count; p++) {
+		if (ns[p] < 0 || nd[p] < 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+		hp[p].srcOff = srcOff[p]; hp[p].dstOff = dstOff[p]; hp[p].colOff = cols; hp[p].ns = ns[p]; hp[p].nd = nd[p];
+		cols += nd[p];
+		maxNs = std::max(maxNs, ns[p]); maxNd = std::max(maxNd, nd[p]);
+	}
+	if (maxNs == 0) return BHIP_OK;
+	const size_t tabBytes = ((size_t)count * sizeof(HamProb) + 255) & ~(size_t)255;
+	BHIP_TRY(work.reserve(ctx, tabBytes + (size_t)std::max<long long>(cols, 1) * sizeof(HamCol)));
+	HamProb* dp = (HamProb*)work.p;
+	HamCol* dcol = (HamCol*)((char*)work.p + tabBytes);
+	BHIP_HIP(ctx, hipMemcpyAsync(dp, hp, (size_t)count * sizeof(HamProb), hipMemcpyHostToDevice, ctx->stream));
+	// integer scores: `score <= maxFitError` is `score <= floor(maxFitError)`; a negative or NaN bound admits nothing
+	int thr = -1;
+	if (maxErr >= 0) thr = maxErr >= 2147483647.0 ? 0x7fffffff : (int)floor(maxErr);
+	const double ops = 2.0 * words;
+	double pairsTotal = 0;
+	for (int p = 0; p < count; p++) pairsTotal += (double)ns[p] * nd[p];
+	{
+		ProfScope ps(ctx, "k_ham_batched_rows", 0, ops * pairsTotal);
+		const dim3 grid((maxNs + 255) / 256, count);
+		if (words == 16) hipLaunchKernelGGL((k_ham_batched<16, false>), grid, dim3(256), 0, ctx->stream, src, dst, dp, words, thr, maxErr, pairs, fit, dcol);
+		else hipLaunchKernelGGL((k_ham_batched<0, false>), grid, dim3(256), 0, ctx->stream, src, dst, dp, words, thr, maxErr, pairs, fit, dcol);
+		BHIP_HIP(ctx, hipGetLastError());
+	}
+	if (backwards && maxNd > 0) {
+		{
+			ProfScope ps(ctx, "k_ham_batched_cols", 0, ops * pairsTotal);
+			const dim3 grid((maxNd + 255) / 256, count);
+			if (words == 16) hipLaunchKernelGGL((k_ham_batched<16, true>), grid, dim3(256), 0, ctx->stream, src, dst, dp, words, thr, maxErr, pairs, fit, dcol);
+			else hipLaunchKernelGGL((k_ham_batched<0, true>), grid, dim3(256), 0, ctx->stream, src, dst, dp, words, thr, maxErr, pairs, fit, dcol);
+			BHIP_HIP(ctx, hipGetLastError());
+		}
+		hipLaunchKernelGGL(k_ham_batched_finish, dim3((maxNs + 255) / 256, count), dim3(256), 0, ctx->stream, dp, dcol, pairs, fit);
+		BHIP_HIP(ctx, hipGetLastError());
+	}
+	// the pinned table is reused by the next call on this ctx: the copy must have been consumed
+	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;
 }
 

@@ -18,6 +18,8 @@ int bhip_assoc_phase1_ham(bhip_ctx* ctx, const int32_t* src, int nsLocal, int sr
 						  double* fit, void* colTop, DevBuf& work);
 int bhip_assoc_phase2(bhip_ctx* ctx, const void* colAll, int nranks, int nd, int nsLocal, int srcBegin, int* pairs, double* fit);
 int bhip_assoc_coltop_size();
+int bhip_assoc_hamming_batched(bhip_ctx* ctx, const int32_t* src, const int32_t* dst, int words, int count, const long long* srcOff, const int* ns,
+							   const long long* dstOff, const int* nd, double maxErr, int backwards, int* pairs, double* fit, DevBuf& work);
 int bhip_launch_integral_u8(bhip_ctx* ctx, const unsigned char* in, long long inImageStride, int inStride, int* out, long long outImageStride, int outStride,
 							int width, int height, int batch);
 
@@ -1327,6 +1329,16 @@ int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double
 // recognises as its own): problem p associates image srcImage[p] (source) with image dstImage[p] (destination) -- same rules as
 // bhip_assoc_l2_f64, no descriptor upload.  pairs / fit are host arrays over the compact key-point index space of the batch: the results
 // of problem p start at the exclusive prefix of the counts of srcImage[p] (every image may be a source at most once per call).
+// batched device form of bhip_assoc_hamming_dev (contract of bhip_assoc_l2_dev_batched): many small problems in three launches
+int bhip_assoc_hamming_dev_batched(bhip_ctx* ctx, const int32_t* dev_src, const int32_t* dev_dst, int words, int count, const long long* srcOff, const int* ns,
+								   const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit) {
+	CHECK_CTX(ctx);
+	if (count < 0 || words <= 0) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad sizes");
+	if (count == 0) return BHIP_OK;
+	if (!srcOff || !ns || !dstOff || !nd || !dev_pairs || !dev_fit) return bhip_fail(ctx, BHIP_ERR_INVALID, "null problem table");
+	return bhip_assoc_hamming_batched(ctx, dev_src, dev_dst, words, count, srcOff, ns, dstOff, nd, maxErr, backwards, dev_pairs, dev_fit, scratchOf(ctx)->work);
+}
+
 // AssociateDescription<TupleDesc_B>.associate() with ScoreAssociateHamming_B on the words still resident from the last detect of a BRIEF
 // object: same contract as bhip_assoc_l2_surf, same rules and results as bhip_assoc_hamming, no descriptor upload.
 int bhip_assoc_hamming_surf(bhip_surf* s, int count, const int* srcImage, const int* dstImage, double maxErr, int backwards, int* pairs, double* fit) {
@@ -1352,11 +1364,15 @@ int bhip_assoc_hamming_surf(bhip_surf* s, int count, const int* srcImage, const 
 	BHIP_HIP(ctx, hipMemsetAsync(sc->c.p, 0xff, (size_t)total * 4, ctx->stream));
 	BHIP_HIP(ctx, hipMemsetAsync(sc->e.p, 0, (size_t)total * 8, ctx->stream));
 	const int32_t* W = s->wordsBuf.as<int32_t>();
+	std::vector<long long> so(count), doff(count);
+	std::vector<int> ns(count), nd(count);
 	for (int p = 0; p < count; p++) {
 		const int a = srcImage[p], b = dstImage[p];
-		BHIP_TRY(bhip_assoc_hamming_dev(ctx, W + (long long)s->starts[a] * s->briefWords, s->det.counts[a], W + (long long)s->starts[b] * s->briefWords,
-										s->det.counts[b], s->briefWords, maxErr, backwards, sc->c.as<int>() + s->starts[a], sc->e.as<double>() + s->starts[a]));
+		so[p] = s->starts[a]; ns[p] = s->det.counts[a];
+		doff[p] = s->starts[b]; nd[p] = s->det.counts[b];
 	}
+	BHIP_TRY(bhip_assoc_hamming_batched(ctx, W, W, s->briefWords, count, so.data(), ns.data(), doff.data(), nd.data(), maxErr, backwards, sc->c.as<int>(),
+										sc->e.as<double>(), sc->work));
 	BHIP_HIP(ctx, hipMemcpyAsync(pairs, sc->c.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(fit, sc->e.p, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));

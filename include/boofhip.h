@@ -216,6 +216,9 @@ int bhip_assoc_hamming_dev(bhip_ctx* ctx, const int32_t* dev_src, int ns, const 
  * pairs/fit are written at the source row offsets. */
 int bhip_assoc_l2_dev_batched(bhip_ctx* ctx, const double* dev_src, const double* dev_dst, int dof, int count, const long long* srcOff,
 							  const int* ns, const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit);
+/* the same for ScoreAssociateHamming_B word lists (`words` ints per row): the consecutive-frame problems of a batch of BRIEF frames */
+int bhip_assoc_hamming_dev_batched(bhip_ctx* ctx, const int32_t* dev_src, const int32_t* dev_dst, int words, int count, const long long* srcOff,
+								   const int* ns, const long long* dstOff, const int* nd, double maxErr, int backwards, int* dev_pairs, double* dev_fit);
 
 /* sharded association: this rank owns source rows [srcBegin, srcBegin+nsLocal) of a global problem with nsGlobal rows and the
  * whole destination set.  Phase 1 computes the local forward matches and, per destination column, the local column top-2

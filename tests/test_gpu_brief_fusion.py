@@ -179,3 +179,49 @@ def test_fusion_refuses_surf_only_calls(api, orc):
     surf.detect(G(api, orc.noise_image(160, 120, 3)))
     w = np.zeros((max(surf.getNumberOfFeatures(), 1), 16), dtype=np.int32)
     assert L.bhip_surf_fetch_brief(surf._h, 0, w.ctypes.data_as(_lib._i32p)) == _lib.BHIP_ERR_INVALID
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("words", [16, 5])
+def test_batched_hamming_association_edge_cases(api, orc, words):
+    """bhip_assoc_hamming_dev_batched against the oracle's greedy Hamming association, problem by problem: ragged sizes incl. empty
+    source / destination sets, exact duplicates (ties: largest index wins forward, a tie in a column kills the match), cutting and
+    degenerate thresholds, with and without backwards validation"""
+    import ctypes as C
+    import torch
+    from boofcv_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(11 + words)
+    sizes = [(300, 280), (1, 1), (0, 40), (37, 0), (513, 257), (64, 64)]
+    sets = []
+    for ns, nd in sizes:
+        a = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(ns, words), dtype=np.int64).astype(np.int32)
+        b = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(nd, words), dtype=np.int64).astype(np.int32)
+        k = min(ns, nd) // 2
+        if k:
+            b[:k] = a[:k]                      # planted exact matches
+            b[k // 2] = b[0]                   # duplicate destination: forward tie -> the larger index
+            flip = rng.integers(0, 32, size=k)
+            b[np.arange(k), 0] ^= (1 << flip).astype(np.int64).astype(np.int32)   # near matches at distance 1
+        if ns > 3:
+            a[3] = a[2]                        # duplicate source: a column tie invalidates both
+        sets.append((a, b))
+    src = np.concatenate([s[0] for s in sets]); dst = np.concatenate([s[1] for s in sets])
+    so = np.concatenate([[0], np.cumsum([len(s[0]) for s in sets])]).astype(np.int64)
+    do_ = np.concatenate([[0], np.cumsum([len(s[1]) for s in sets])]).astype(np.int64)
+    ns = np.array([len(s[0]) for s in sets], dtype=np.int32); nd = np.array([len(s[1]) for s in sets], dtype=np.int32)
+    ctx = api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream)
+    dsrc = torch.from_numpy(src).to("cuda:0"); ddst = torch.from_numpy(dst if len(dst) else np.zeros((1, words), np.int32)).to("cuda:0")
+    LL, I = C.POINTER(C.c_longlong), C.POINTER(C.c_int)
+    for maxErr, backwards in ((api.Double_MAX_VALUE, 1), (api.Double_MAX_VALUE, 0), (words * 16 - 20.5, 1), (0.0, 1), (-1.0, 0)):
+        pairs = torch.full((len(src),), 7, dtype=torch.int32, device="cuda:0"); fit = torch.zeros(len(src), dtype=torch.float64, device="cuda:0")
+        st = L.bhip_assoc_hamming_dev_batched(ctx._h, C.c_void_p(dsrc.data_ptr()), C.c_void_p(ddst.data_ptr()), words, len(sets), so[:-1].copy().ctypes.data_as(LL),
+                                              ns.ctypes.data_as(I), do_[:-1].copy().ctypes.data_as(LL), nd.ctypes.data_as(I), maxErr, backwards,
+                                              C.c_void_p(pairs.data_ptr()), C.c_void_p(fit.data_ptr()))
+        assert st == 0, L.bhip_last_error(ctx._h)
+        gp, gf = pairs.cpu().numpy(), fit.cpu().numpy()
+        for p, (a, b) in enumerate(sets):
+            ep, ef = orc.associate_hamming(a, b, maxErr, bool(backwards), threads=THREADS)
+            assert np.array_equal(gp[so[p]:so[p + 1]], ep), (p, maxErr, backwards)
+            assert np.array_equal(gf[so[p]:so[p + 1]], ef), (p, maxErr, backwards)
+    ctx.close()
