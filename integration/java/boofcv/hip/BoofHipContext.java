@@ -28,6 +28,22 @@ public final class BoofHipContext {
 		return h[0];
 	}
 
+	/** A context of its own for one provider object (ADVICE r2: a provider built on one thread and used on another must not share the
+	 *  constructing thread's context): created here, destroyed by the provider's close().  The native library tolerates any destroy order
+	 *  (include/boofhip.h, "handles may be destroyed in any order"). */
+	public static long create() {
+		long[] h = new long[1];
+		int status = BoofHip.ctxCreate(device, h);
+		if (status != 0 || h[0] == 0) throw new RuntimeException("boofhip: bhip_ctx_create(" + device + ") failed with status " + status);
+		return h[0];
+	}
+
+	/** Releases the calling thread's shared context (the BOverride hooks use it); call from a worker thread before it exits. */
+	public static void closeThreadContext() {
+		long[] h = CTX.get();
+		if (h != null) { BoofHip.ctxDestroy(h[0]); CTX.remove(); }
+	}
+
 	private static ByteBuffer struct(int bytes) { return ByteBuffer.allocateDirect(bytes).order(ByteOrder.nativeOrder()); }
 
 	/** bhip_fh_cfg {float detectThreshold; int extractRadius, maxFeaturesPerScale, initialSampleSize, initialSize, numberScalesPerOctave,

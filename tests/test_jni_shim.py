@@ -36,10 +36,21 @@ def test_provider_sources_call_existing_natives():
     natives = set(re.findall(r"native \S+ (\w+)\(", j_src)) | {"check"}
     d = os.path.join(ROOT, "integration", "java", "boofcv", "hip")
     used = set()
-    for f in os.listdir(d):
+    sources = sorted(f for f in os.listdir(d) if f.endswith(".java"))
+    for f in sources:
         if f != "BoofHip.java":
             used |= set(re.findall(r"BoofHip\.(\w+)\(", open(os.path.join(d, f)).read()))
     assert used and used <= natives, used - natives
+    # every provider class INTEGRATION.md names exists as a source file, and balances its braces (there is no javac here)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"\b(\w+Hip\w*)\b", doc)) - {"BoofHip"}
+    have = {f[:-5] for f in sources}
+    for f in sources:   # nested classes count (NonMaxHip lives inside BoofHipOverrides)
+        have |= set(re.findall(r"\bclass (\w+)", open(os.path.join(d, f)).read()))
+    assert named <= have, "INTEGRATION.md names provider classes that have no source: %s" % sorted(named - have)
+    for f in sources:
+        src = open(os.path.join(d, f)).read()
+        assert src.count("{") == src.count("}") and src.count("(") == src.count(")"), f
     # the install() of the overrides assigns every hook field of the four BOverride classes the library implements
     ov = open(os.path.join(d, "BoofHipOverrides.java")).read()
     for hook in ("BOverrideConvolveImage.horizontal", "BOverrideConvolveImage.vertical", "BOverrideConvolveImage.convolve", "BOverrideConvolveImageNormalized.horizontal",
