@@ -457,6 +457,7 @@ struct bhip_surf {
 	bool brief = false;
 	int briefRadius = 0, briefPoints = 0, briefWords = 0;
 	DevBuf briefTab, wordsBuf;   // [samplePoints | compare] on the device; words of the whole batch, compact [total][briefWords]
+	bool briefPatch = false;            // the definition fits the LDS-patch kernel
 	const int* briefBorrow = nullptr;   // chunk worker: the owner's table
 	const int* briefSample() const { return briefBorrow ? briefBorrow : briefTab.as<int>(); }
 	const int* briefCompare() const { return briefSample() + briefCompareOff; }
@@ -569,7 +570,7 @@ static int surfRun(bhip_surf* s, ImgView in, int batch, int planarBands = 0, boo
 			for (int c : s->det.counts) maxCount = std::max(maxCount, c);
 			BHIP_TRY(bhip_launch_brief(ctx, in.data, u8 ? W : in.stride, W, H, s->briefRadius, s->briefPoints, s->briefSample(), s->briefCompare(),
 									   (const double*)s->det.sorted.p, (int)total, s->wordsBuf.as<int>(), u8, batch, u8 ? (long long)W * H : in.imageStride,
-									   s->startBuf.as<int>(), maxCount, (int)(sizeof(KeyPoint) / 8), (long long)s->det.cap * (long long)(sizeof(KeyPoint) / 8)));
+									   s->startBuf.as<int>(), maxCount, (int)(sizeof(KeyPoint) / 8), (long long)s->det.cap * (long long)(sizeof(KeyPoint) / 8), s->briefPatch));
 		}
 		BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		s->haveResult = true;
@@ -637,7 +638,7 @@ static int surfRunChunked(bhip_surf* s, int width, int height, int batch, size_t
 			// the worker samples with the owner's definition (it borrows the device table; briefTab stays empty so it is never freed twice)
 			bhip_surf* w0 = s->worker;
 			w0->brief = true; w0->briefRadius = s->briefRadius; w0->briefPoints = s->briefPoints; w0->briefWords = s->briefWords;
-			w0->briefBorrow = s->briefTab.as<int>(); w0->briefCompareOff = s->briefCompareOff;
+			w0->briefBorrow = s->briefTab.as<int>(); w0->briefCompareOff = s->briefCompareOff; w0->briefPatch = s->briefPatch;
 		}
 		BHIP_HIP(ctx, hipStreamCreateWithFlags(&s->copyStream, hipStreamNonBlocking));
 	}
@@ -765,6 +766,13 @@ static void surfReleaseDevice(bhip_surf* s) {
 static void surfOrphanChildren(bhip_ctx* ctx) {
 	for (bhip_surf* s : registry().surfs)
 		if (s->ctx == ctx) surfReleaseDevice(s);
+}
+
+// every sample point the pairs use lies within [-radius, radius]^2: the LDS-patch BRIEF kernel may be used (ip.hip, k_brief_patch)
+static bool briefPatchOk(const int32_t* samplePoints, int nSamples, int radius) {
+	for (int i = 0; i < 2 * nSamples; i++)
+		if (samplePoints[i] < -radius || samplePoints[i] > radius) return false;
+	return radius >= 0 && radius <= 40;
 }
 
 extern "C" {
@@ -980,6 +988,7 @@ int bhip_surf_create_brief(bhip_ctx* ctx, const bhip_fh_cfg* fh, int radius, int
 	s->briefRadius = radius; s->briefPoints = numPoints; s->briefWords = (numPoints + 31) / 32;
 	const size_t nSample = (size_t)(maxIdx + 1) * 2, nCompare = (size_t)numPoints * 2;
 	s->briefCompareOff = nSample;
+	s->briefPatch = briefPatchOk(samplePoints, maxIdx + 1, radius);
 	int st = s->briefTab.reserve(ctx, (nSample + nCompare) * 4);
 	if (st == BHIP_OK && hipMemcpy(s->briefTab.p, samplePoints, nSample * 4, hipMemcpyHostToDevice) != hipSuccess) st = bhip_fail(ctx, BHIP_ERR_HIP, "BRIEF table upload");
 	if (st == BHIP_OK && hipMemcpy(s->briefTab.as<int>() + nSample, compare, nCompare * 4, hipMemcpyHostToDevice) != hipSuccess) st = bhip_fail(ctx, BHIP_ERR_HIP, "BRIEF table upload");
@@ -1775,7 +1784,8 @@ int bhip_brief_u8(bhip_ctx* ctx, const uint8_t* img, int start, int stride, int 
 	BHIP_HIP(ctx, hipMemcpyAsync(dSample, samplePoints, (size_t)(maxIdx + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(dCompare, compare, (size_t)numPoints * 8, hipMemcpyHostToDevice, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(sc->c.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-	BHIP_TRY(bhip_launch_brief(ctx, (const float*)sc->a.p, width, width, height, radius, numPoints, dSample, dCompare, sc->c.as<double>(), n, sc->d.as<int>(), true));
+	BHIP_TRY(bhip_launch_brief(ctx, (const float*)sc->a.p, width, width, height, radius, numPoints, dSample, dCompare, sc->c.as<double>(), n, sc->d.as<int>(), true, 1, 0, nullptr, 0, 2, 0,
+							   briefPatchOk(samplePoints, maxIdx + 1, radius)));
 	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->d.p, (size_t)n * words * 4, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;
@@ -1787,6 +1797,8 @@ int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int w
 	CHECK_IMG(ctx, img, stride, width, height);
 	if (numPoints <= 0 || !samplePoints || !compare || n < 0 || (n > 0 && (!xy || !out))) return bhip_fail(ctx, BHIP_ERR_INVALID, "bad BRIEF arguments");
 	if (n == 0) return BHIP_OK;
+	for (int i = 0; i < 2 * numPoints; i++)
+		if (compare[i] < 0 || compare[i] >= numPoints) return bhip_fail(ctx, BHIP_ERR_INVALID, "pair index outside the sample point list");
 	const int words = (numPoints + 31) / 32;
 	CtxScratch* sc = scratchOf(ctx);
 	BHIP_TRY(uploadImage(ctx, sc->a, img, start, stride, width, height));
@@ -1798,7 +1810,8 @@ int bhip_brief_f32(bhip_ctx* ctx, const float* img, int start, int stride, int w
 	BHIP_HIP(ctx, hipMemcpyAsync(dsp, samplePoints, (size_t)numPoints * 8, hipMemcpyHostToDevice, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(dcp, compare, (size_t)numPoints * 8, hipMemcpyHostToDevice, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(sc->c.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-	BHIP_TRY(bhip_launch_brief(ctx, sc->a.as<float>(), width, width, height, radius, numPoints, dsp, dcp, sc->c.as<double>(), n, sc->e.as<int>()));
+	BHIP_TRY(bhip_launch_brief(ctx, sc->a.as<float>(), width, width, height, radius, numPoints, dsp, dcp, sc->c.as<double>(), n, sc->e.as<int>(), false, 1, 0, nullptr, 0, 2, 0,
+							   briefPatchOk(samplePoints, numPoints, radius)));
 	BHIP_HIP(ctx, hipMemcpyAsync(out, sc->e.p, (size_t)n * words * 4, hipMemcpyDeviceToHost, ctx->stream));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BHIP_OK;
@@ -1931,7 +1944,8 @@ int bhip_brief_dev_f32(bhip_ctx* ctx, const float* dev_img, long long imageStrid
 	BHIP_HIP(ctx, hipMemcpyAsync(dSample, samplePoints, nSample * 4, hipMemcpyHostToDevice, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(dCompare, compare, nCompare * 4, hipMemcpyHostToDevice, ctx->stream));
 	BHIP_HIP(ctx, hipMemcpyAsync(dStart, start, (size_t)(batch + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-	BHIP_TRY(bhip_launch_brief(ctx, dev_img, stride, width, height, radius, numPoints, dSample, dCompare, dev_xy, n, dev_out, false, batch, imageStride, dStart, maxCount));
+	BHIP_TRY(bhip_launch_brief(ctx, dev_img, stride, width, height, radius, numPoints, dSample, dCompare, dev_xy, n, dev_out, false, batch, imageStride, dStart, maxCount, 2, 0,
+							   briefPatchOk(samplePoints, maxIdx + 1, radius)));
 	BHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host tables were handed to async copies
 	return BHIP_OK;
 }

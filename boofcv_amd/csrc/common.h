@@ -230,7 +230,9 @@ int bhip_launch_grad_intensity(bhip_ctx* ctx, int kind, const float* dx, const f
 							   long long oImageStride, int oStride, int width, int height, int batch);
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out, bool u8 = false, int batch = 1, long long imageStride = 0,
-					  const int* start = nullptr, int maxCount = 0, int xyStride = 2, long long xyImageStride = 0);
+					  const int* start = nullptr, int maxCount = 0, int xyStride = 2, long long xyImageStride = 0, bool patchOk = false);
+// patchOk: every sample point of the definition lies within [-radius, radius]^2 (checked on the host where the table is at hand), so the
+// LDS-patch kernel may be used; otherwise the gather kernel runs
 // stand-alone strict block NMS over a batch (detect.hip): bitmap of accepted blocks + the pixel's position inside its block
 int bhip_launch_nonmax_blocks(bhip_ctx* ctx, const float* img, long long imageStride, int stride, int w, int h, int batch, int radius, float threshold, int border,
 							  unsigned int* bitmap, int bitmapWords, unsigned short* posInBlock, int nbx, int nby);

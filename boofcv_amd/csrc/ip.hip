@@ -1034,17 +1034,116 @@ __global__ __launch_bounds__(256) void k_brief(BriefParams P) {
 	P.out[(long long)p * P.words + word] = (int)desc;
 }
 
+// LDS-patch form (the normal path): one wavefront per key point.  The (2R+1)^2 neighbourhood of the point is staged once with row-wise
+// loads (33 rows of 132 bytes for R = 16) and the 2 x numPoints samples are LDS reads -- against two scattered global reads per pair in
+// the per-word kernel above.  The pair table is resolved once per workgroup into patch offsets (and the raw sample coordinates, for
+// the border rules).  Interior points and every GrayU8 point: lane l takes pairs 8l .. 8l+7 of each run of 512, builds its byte of the
+// word, the four lanes of a quad OR their bytes together (bit of pair j in a word of `cnt` pairs: cnt - 1 - j, i.e. the first pair ends
+// up in the top bit of a full word -- the reference's shift-and-add loop).  GrayF32 border points skip pairs without shifting, so the bit
+// position depends on the pairs before: one lane per word walks its pairs in order, still from the patch.
+#define BRIEF_KP_PER_WAVE 4
+template <class PIX>
+__global__ __launch_bounds__(256) void k_brief_patch(BriefParams P) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char briefLds[];
+	const int R = P.radius, PW = 2 * R + 1, PP = PW * PW;
+	unsigned int* offs = (unsigned int*)briefLds;                 // [numPoints] patch offset of sample A | patch offset of sample B << 16
+	unsigned int* xy8 = offs + P.numPoints;                       // [numPoints] (ax, ay, bx, by) as signed bytes
+	float* patches = (float*)(xy8 + P.numPoints);                 // [4 waves][PP]
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	for (int j = threadIdx.x; j < P.numPoints; j += blockDim.x) {
+		const int ia = P.compare[2 * j], ib = P.compare[2 * j + 1];
+		const int ax = P.samplePoints[2 * ia], ay = P.samplePoints[2 * ia + 1], bx = P.samplePoints[2 * ib], by = P.samplePoints[2 * ib + 1];
+		offs[j] = (unsigned)((ay + R) * PW + ax + R) | ((unsigned)((by + R) * PW + bx + R) << 16);
+		xy8[j] = (unsigned)(ax & 0xff) | ((unsigned)(ay & 0xff) << 8) | ((unsigned)(bx & 0xff) << 16) | ((unsigned)(by & 0xff) << 24);
+	}
+	__syncthreads();
+	const int first = P.start ? P.start[blockIdx.y] : 0;
+	const int count = P.start ? P.start[blockIdx.y + 1] - first : P.n;
+	const PIX* __restrict__ img = (const PIX*)P.img + (long long)blockIdx.y * P.imageStride;
+	float* patch = patches + wave * PP;
+	const int W = P.width, H = P.height;
+	for (int it = 0; it < BRIEF_KP_PER_WAVE; it++) {
+		const int pl = (blockIdx.x * 4 + wave) * BRIEF_KP_PER_WAVE + it;   // wave-uniform
+		if (pl >= count) break;
+		const int p = first + pl;
+		const double* pt = P.xyImageStride ? P.xy + (long long)blockIdx.y * P.xyImageStride + (long long)pl * P.xyStride : P.xy + (long long)p * P.xyStride;
+		const int c_x = (int)pt[0], c_y = (int)pt[1];
+		const bool inside = !(c_x - R < 0 || c_x + R >= W || c_y - R < 0 || c_y + R >= H);
+		__builtin_amdgcn_wave_barrier();
+		for (int i = lane; i < PP; i += 64) {
+			const int py = i / PW, px = i - py * PW;
+			const int gx = c_x - R + px, gy = c_y - R + py;
+			float v = 0.f;
+			if (inside || (gx >= 0 && gx < W && gy >= 0 && gy < H)) v = (float)img[(long long)gy * P.stride + gx];
+			patch[i] = v;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		int* out = P.out + (long long)p * P.words;
+		if (inside || sizeof(PIX) == 1) {
+			for (int base = 0; base < P.numPoints; base += 512) {
+				const int j0 = base + lane * 8;
+				const int wordBase = j0 & ~31;
+				const int cnt = min(32, P.numPoints - wordBase);   // pairs in this lane's word
+				unsigned int bits = 0;
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const int j = j0 + q;
+					if (j < P.numPoints) {
+						const unsigned int o = offs[j];
+						bool lt = patch[o & 0xffffu] < patch[o >> 16];
+						if (!inside) {
+							const unsigned int c = xy8[j];
+							const int ax = (int)(signed char)(c & 0xff) + c_x, ay = (int)(signed char)((c >> 8) & 0xff) + c_y;
+							const int bx = (int)(signed char)((c >> 16) & 0xff) + c_x, by = (int)(signed char)(c >> 24) + c_y;
+							lt = lt && ax >= 0 && ax < W && ay >= 0 && ay < H && bx >= 0 && bx < W && by >= 0 && by < H;
+						}
+						bits |= (lt ? 1u : 0u) << (cnt - 1 - (j - wordBase));
+					}
+				}
+				bits |= __shfl_xor(bits, 1, 64);
+				bits |= __shfl_xor(bits, 2, 64);
+				if ((lane & 3) == 0 && wordBase < P.numPoints) out[wordBase >> 5] = (int)bits;
+			}
+		} else {
+			// ImplDescribeBinaryCompare_F32.processBorder: a pair with a sample outside the frame is skipped WITHOUT shifting the word
+			for (int word = lane; word < P.words; word += 64) {
+				const int i0 = word * 32, i1 = min(P.numPoints, i0 + 32);
+				unsigned int desc = 0;
+				for (int j = i0; j < i1; j++) {
+					const unsigned int c = xy8[j];
+					const int ax = (int)(signed char)(c & 0xff) + c_x, ay = (int)(signed char)((c >> 8) & 0xff) + c_y;
+					const int bx = (int)(signed char)((c >> 16) & 0xff) + c_x, by = (int)(signed char)(c >> 24) + c_y;
+					if (ax >= 0 && ax < W && ay >= 0 && ay < H && bx >= 0 && bx < W && by >= 0 && by < H) {
+						const unsigned int o = offs[j];
+						desc = desc * 2u + (patch[o & 0xffffu] < patch[o >> 16] ? 1u : 0u);
+					}
+				}
+				out[word] = (int)desc;
+			}
+		}
+	}
+}
+
 // start == nullptr: n points on one image.  Otherwise `batch` images and device prefix `start` (batch+1); maxCount = largest per-image count.
 int bhip_launch_brief(bhip_ctx* ctx, const float* img, int stride, int width, int height, int radius, int numPoints, const int* samplePoints,
 					  const int* compare, const double* xy, int n, int* out, bool u8, int batch, long long imageStride, const int* start, int maxCount,
-					  int xyStride, long long xyImageStride) {
+					  int xyStride, long long xyImageStride, bool patchOk) {
 	if (n <= 0) return BHIP_OK;
 	BriefParams P{img, imageStride, stride, width, height, radius, numPoints, (numPoints + 31) / 32, n, samplePoints, compare, xy, out, start, xyStride, xyImageStride};
 	const long long total = (long long)(start ? maxCount : n) * P.words;
 	if (total <= 0) return BHIP_OK;
 	dim3 grid((unsigned)((total + 255) / 256), start ? batch : 1);
-	ProfScope prof(ctx, "k_brief");
-	if (u8) hipLaunchKernelGGL(k_brief<unsigned char>, grid, dim3(256), 0, ctx->stream, P);
+	// per point: the (2R+1)^2 patch read once + the words written
+	ProfScope prof(ctx, "k_brief", (double)n * ((double)(2 * radius + 1) * (2 * radius + 1) * (u8 ? 1 : 4) + 4.0 * P.words));
+	const size_t patchLds = (size_t)numPoints * 8 + (size_t)4 * (2 * radius + 1) * (2 * radius + 1) * 4;
+	if (patchOk && radius <= 40 && numPoints <= 4096 && patchLds <= 64 * 1024 && !bhip_env_flag("BHIP_BRIEF_GATHER")) {
+		const long long pts = start ? maxCount : n;
+		dim3 pgrid((unsigned)((pts + 4 * BRIEF_KP_PER_WAVE - 1) / (4 * BRIEF_KP_PER_WAVE)), start ? batch : 1);
+		if (u8) hipLaunchKernelGGL(k_brief_patch<unsigned char>, pgrid, dim3(256), patchLds, ctx->stream, P);
+		else hipLaunchKernelGGL(k_brief_patch<float>, pgrid, dim3(256), patchLds, ctx->stream, P);
+	} else if (u8) hipLaunchKernelGGL(k_brief<unsigned char>, grid, dim3(256), 0, ctx->stream, P);
 	else hipLaunchKernelGGL(k_brief<float>, grid, dim3(256), 0, ctx->stream, P);
 	BHIP_HIP(ctx, hipGetLastError());
 	return BHIP_OK;

@@ -225,3 +225,33 @@ def test_batched_hamming_association_edge_cases(api, orc, words):
             assert np.array_equal(gp[so[p]:so[p + 1]], ep), (p, maxErr, backwards)
             assert np.array_equal(gf[so[p]:so[p + 1]], ef), (p, maxErr, backwards)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius,npts", [(16, 512), (9, 70), (3, 33), (20, 600)])
+def test_brief_patch_and_gather_kernels_agree_with_the_oracle(api, orc, monkeypatch, radius, npts):
+    """the LDS-patch kernel (one wave per point) and the per-word gather kernel (BHIP_BRIEF_GATHER=1, also the fall-back for definitions whose
+    samples leave the patch) against the oracle: word counts that are no multiple of 32 (the last word is right aligned), interior and
+    border points, GrayF32 (skip without shift at the border) and GrayU8 (shift for every pair)"""
+    rng = np.random.default_rng(radius * 1000 + npts)
+    sp = rng.integers(-radius, radius + 1, size=(npts, 2)).astype(np.int32)
+    cp = np.stack([np.arange(npts), rng.integers(0, npts, size=npts)], axis=1).astype(np.int32)
+    w, h = 190, 141
+    img = orc.noise_image(w, h, 5)
+    xy = np.concatenate([rng.uniform(0, w, size=(300, 1)), rng.uniform(0, h, size=(300, 1))], axis=1)
+    xy = np.concatenate([xy, [[0, 0], [w - 0.1, h - 0.1], [radius, radius], [radius - 0.1, 70], [w - 1 - radius, h - 1 - radius], [w - radius, h - radius]]])
+    ref = orc.brief_describe(img, xy, radius, sp, cp)
+    u8 = (img.array() * 2.5).astype(np.uint8)
+    ref8 = orc.brief_describe_u8(u8, xy, radius, sp, cp)
+    for gather in (False, True):
+        if gather:
+            monkeypatch.setenv("BHIP_BRIEF_GATHER", "1")
+        b = api.DescribePointBrief(radius, sp, cp); b.setImage(G(api, img))
+        assert np.array_equal(b.processAll(xy), ref), "F32 gather=%s" % gather
+        b.setImage(api.GrayU8(w, h, u8.reshape(-1).copy()))
+        assert np.array_equal(b.processAll(xy), ref8), "U8 gather=%s" % gather
+    monkeypatch.delenv("BHIP_BRIEF_GATHER")
+    # samples outside [-radius, radius]: the library must still answer (gather kernel), as the reference does for any definition
+    sp2 = sp.copy(); sp2[0] = (radius + 3, 0)
+    b = api.DescribePointBrief(radius, sp2, cp); b.setImage(G(api, img))
+    assert np.array_equal(b.processAll(xy), orc.brief_describe(img, xy, radius, sp2, cp))
