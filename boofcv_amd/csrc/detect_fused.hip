@@ -511,6 +511,42 @@ __global__ __launch_bounds__(NTT) void k_detect_fused_fixed(FusedParams P) {
 	const int stride = P.ii.stride, W = P.ii.width, H = P.ii.height;
 	const int X0 = (x0 - R) * SKIP - G::rFmax - 1, Y0 = (y0 - R) * SKIP - G::rFmax - 1;
 	bool staged = false;
+	// Interior tiles (all but those along the image frame): the patch lies inside the image, so its rows go from global memory straight
+	// into LDS (global_load_lds_dword: lane l of an instruction delivers its dword to M0-base + 4 l; no VGPR round trip, no ds_write, no
+	// per-element address arithmetic -- staging used to be a quarter of this kernel's vector instructions).  One instruction per patch
+	// row and 64-column chunk (SKIP == 1) or per row and column phase (SKIP > 1: the lanes read every SKIP-th column, which lands
+	// them contiguously in that phase's plane).  The barrier below waits for the loads (vmcnt) before anything reads the patch.
+	{
+#ifdef BHIP_EXPERIMENTS
+		const bool dmaOff = BHIP_ABLATE(P, 16);
+#else
+		const bool dmaOff = false;
+#endif
+		// (measured: octave 0 1.10 -> 1.03 ms per 64 frames; on octave 1 the stride-2 dword form needs 276 instructions per tile and is
+		// 6 % slower than the 16-byte register-staged form below, so only SKIP == 1 takes this path)
+		const bool dmaOk = SKIP == 1 && !dmaOff && !BHIP_ABLATE(P, 4) && X0 >= 0 && Y0 >= 0 && X0 + G::IW <= W && Y0 + G::IH <= H;
+		if (dmaOk) {
+			const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+			const T* src0 = d + (long long)Y0 * stride + X0;
+			constexpr int PCOLS = (G::IW + SKIP - 1) / SKIP;          // columns of one phase plane
+			constexpr int CHUNKS = (PCOLS + 63) / 64;
+			for (int ry = wave; ry < G::IH; ry += G::NW) {
+				const T* srow = src0 + (long long)ry * stride;
+#pragma unroll
+				for (int ph = 0; ph < SKIP; ph++) {
+#pragma unroll
+					for (int cc = 0; cc < CHUNKS; cc++) {
+						const int j = cc * 64 + lane;                   // column slot inside the plane
+						if (j * SKIP + ph < G::IW)
+							__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srow + j * SKIP + ph),
+															 (__attribute__((address_space(3))) void*)(iiT + ph * G::plane + ry * G::IWp + cc * 64), 4, 0, 0);
+					}
+				}
+			}
+			staged = true;
+		}
+	}
+	// (fall-back forms below: frame tiles, and the earlier register-staged interior forms kept for cross-checks)
 	// Interior tiles (all but those along the image frame): the patch lies inside the image and, with the tile pitch a multiple of four
 	// columns, starts on (SKIP == 1) or two columns after (SKIP == 2) a 16-byte boundary -- whole rows are fetched with 16-byte loads,
 	// no per-element guards.  One (row, 4-column group) item per thread and pass; all loads are issued before the first LDS store.
@@ -519,7 +555,7 @@ __global__ __launch_bounds__(NTT) void k_detect_fused_fixed(FusedParams P) {
 		constexpr int IW4 = (G::IW + SH + 3) / 4;
 		constexpr int ITEMS = G::IH * IW4, NIT = (ITEMS + G::NT - 1) / G::NT;
 		const T* src0 = d + (long long)Y0 * stride + (X0 - SH);
-		const bool vecOk = !BHIP_ABLATE(P, 4) && X0 - SH >= 0 && Y0 >= 0 && X0 - SH + 4 * IW4 <= W && Y0 + G::IH <= H && (stride & 3) == 0 &&
+		const bool vecOk = !staged && !BHIP_ABLATE(P, 4) && X0 - SH >= 0 && Y0 >= 0 && X0 - SH + 4 * IW4 <= W && Y0 + G::IH <= H && (stride & 3) == 0 &&
 						   (((unsigned long long)src0) & 15ull) == 0;
 		if (vecOk) {
 			int4 v[NIT];
