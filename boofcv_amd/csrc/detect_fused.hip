@@ -702,22 +702,31 @@ __global__ __launch_bounds__(NTT) void k_detect_fused_fixed(FusedParams P) {
 	}
 
 	// ---- strict (2R+1)^2 maxima of the two mid levels, in two steps so that no wave walks the full window for one or two lanes:
-	//   1. thread = one core column of one (level, row-phase) slice: threshold, then the four direct neighbours (most pixels above the
-	//      threshold lose against one of them); what is left (a few per cent) is compacted into a workgroup-wide list;
+	//   1. thread = one core column of one mid level within a band of rows (a wave = both levels x 32 columns, one band per wave): it
+	//      walks down its rows with the value above / at / below in registers -- one LDS read per pixel -- and tests the threshold and
+	//      the two vertical neighbours; the few pixels that pass read their two horizontal neighbours.  What is left (a few per cent:
+	//      most pixels above the threshold lose against a direct neighbour) is compacted into a workgroup-wide list;
 	//   2. one listed pixel per thread: frame tests, the full window, the ignore border -> survivor list.
 	{
-		constexpr int SL = G::NT / G::ITW;         // row slices a pass of the workgroup covers (ITW lanes per row)
-		const int px = tid & (G::ITW - 1), slice = tid / G::ITW;
-		for (int row = slice; row < P.nmid * G::TY && !BHIP_ABLATE(P, 2); row += SL) {
-			const int m = row / G::TY, py = row - m * G::TY;
-			if (px >= G::TX) continue;
-			const float* mid = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2) + (py + R) * G::ITp + (px + R);
-			const float val = mid[0];
-			if (!(val >= P.threshold) || val == FLT_MAX) continue;
-			const float n0 = mid[-1], n1 = mid[1], n2 = mid[-G::ITp], n3 = mid[G::ITp];
-			if (n0 >= val || n1 >= val || n2 >= val || n3 >= val) continue;
-			// a pixel above its four direct neighbours has none of them in the list: at most every second pixel, NCAND holds them all
-			candList[atomicAdd(candCount, 1)] = (unsigned short)((m << 12) | (py << 6) | px);
+		static_assert(G::ITW == 32, "a wave = two mid levels x 32 columns");
+		constexpr int RB = (G::TY + G::NW - 1) / G::NW;     // rows per band
+		const int px = tid & 31, m = (tid >> 5) & 1, band = tid >> 6;
+		const int py0 = band * RB;
+		if (px < G::TX && m < P.nmid && py0 < G::TY && !BHIP_ABLATE(P, 2)) {
+			const float* col = ((m == 0 ? M0.level : M1.level) == 1 ? mid1 : mid2) + (py0 + R) * G::ITp + (px + R);
+			float prev = col[-G::ITp], cur = col[0];
+#pragma unroll
+			for (int k = 0; k < RB; k++) {
+				if (py0 + k < G::TY) {
+					const float next = col[(k + 1) * G::ITp];
+					if (cur >= P.threshold && cur != FLT_MAX && !(prev >= cur) && !(next >= cur)) {
+						const float left = col[k * G::ITp - 1], right = col[k * G::ITp + 1];
+						// a pixel above its four direct neighbours has none of them in the list: at most every second pixel, NCAND holds them all
+						if (!(left >= cur) && !(right >= cur)) candList[atomicAdd(candCount, 1)] = (unsigned short)((m << 12) | ((py0 + k) << 6) | px);
+					}
+					prev = cur; cur = next;
+				}
+			}
 		}
 	}
 	__syncthreads();
