@@ -1525,10 +1525,14 @@ int bhip_gaussian_f32(bhip_ctx* ctx, const float* in, int inStart, int inStride,
 	CtxScratch* sc = scratchOf(ctx);
 	const int pitch = pitch4(width);
 	BHIP_TRY(uploadImage(ctx, sc->a, in, inStart, inStride, width, height, pitch));
-	BHIP_TRY(sc->b.reserve(ctx, (size_t)pitch * height * 4));
 	BHIP_TRY(sc->c.reserve(ctx, (size_t)pitch * height * 4));
-	BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, sc->a.as<float>(), pitch, width, height, sc->b.as<float>(), pitch));
-	BHIP_TRY(bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->b.as<float>(), pitch, width, height, sc->c.as<float>(), pitch));
+	bool fused = false;
+	BHIP_TRY(bhip_launch_blur_fused(ctx, k.data(), kw, sc->a.as<float>(), pitch, width, height, sc->c.as<float>(), pitch, 1, 0, 0, &fused));
+	if (!fused) {
+		BHIP_TRY(sc->b.reserve(ctx, (size_t)pitch * height * 4));
+		BHIP_TRY(bhip_launch_conv(ctx, false, true, k.data(), kw, koff, sc->a.as<float>(), pitch, width, height, sc->b.as<float>(), pitch));
+		BHIP_TRY(bhip_launch_conv(ctx, true, true, k.data(), kw, koff, sc->b.as<float>(), pitch, width, height, sc->c.as<float>(), pitch));
+	}
 	return downloadImage(ctx, sc->c.p, out, outStart, outStride, width, height, pitch);
 }
 
@@ -1865,6 +1869,9 @@ int bhip_gaussian_dev_f32(bhip_ctx* ctx, const float* dev_in, long long inImageS
 	std::vector<float> k = bhip_gaussian1d_f32(sigma, radius);
 	const int kw = (int)k.size(), koff = kw / 2;
 	CtxScratch* sc = scratchOf(ctx);
+	bool fused = false;
+	BHIP_TRY(bhip_launch_blur_fused(ctx, k.data(), kw, dev_in, inStride, width, height, dev_out, outStride, batch, inImageStride, outImageStride, &fused));
+	if (fused) return BHIP_OK;
 	const int pitch = pitch4(width);
 	const long long tmpImage = (long long)pitch * height;
 	BHIP_TRY(sc->ipTmp.reserve(ctx, (size_t)tmpImage * 4 * batch));

@@ -406,6 +406,129 @@ __global__ __launch_bounds__(256) void k_conv_v_stream(ConvParams P) {
 	}
 }
 
+// ---- Gaussian blur in ONE pass over the image (BlurImageOps.gaussian = ConvolveImageNormalized.horizontal into `storage`, then
+// ConvolveImageNormalized.vertical into the output: I:alg/filter/blur/BlurImageOps.java:406-425) for the reference's unrolled widths.
+// A wave owns a strip of 256 columns x BF_ROWS output rows and walks down the input rows once: a row is loaded (16 bytes per lane),
+// filtered horizontally in registers -- the value the reference would have stored in `storage`, border columns included -- and pushed
+// into a register ring of the last KW filtered rows, from which the vertical filter produces one output row per input row.  The
+// intermediate image never exists: 4P read + 4P written (+ 2R re-read rows per strip) instead of 16P for the two passes.  Every value is
+// formed by the reference's expression for its position class, in its tap order:
+//   interior  total = s0*k0; total += s_i*k_i                                   (ConvolveImageUnrolled_SB_F32_F32.java:152-180,384-425)
+//   border    weight += k; total += s*k over the taps inside the image; total / weight   (ConvolveNormalized_JustBorder_SB.java:60-88,108-140)
+#define BF_ROWS 32   // output rows per wave strip
+// Measured alternatives that lost (A/B in one run, 64 x 1080p, r = 2 / r = 5: this form 0.27 / 0.64 ms): chunk-bounds tests hoisted out of
+// the row loop with plain 16-byte loads 0.31 / 0.87 ms; one row of look-ahead instead of two for widths 9, 11 (107 instead of 126
+// registers) 0.76 ms; 64-row strips for widths 9, 11 0.65 ms at 1080p but 0.31 instead of 0.25 ms on 8 x 4K.
+template <int KW>
+__device__ __forceinline__ float blurTapsInterior(const float (&v)[KW], const float* k) {
+	float total = v[0] * k[0];
+#pragma unroll
+	for (int i = 1; i < KW; i++) total += v[i] * k[i];
+	return total;
+}
+// first: index of tap 0 along the filtered axis (pos - R); extent: image size along that axis.  Taps outside [0, extent) are skipped.
+template <int KW>
+__device__ __forceinline__ float blurTapsBorder(const float (&v)[KW], const float* k, int first, int extent) {
+	float total = 0, weight = 0;
+#pragma unroll
+	for (int i = 0; i < KW; i++) {
+		const bool in = first + i >= 0 && first + i < extent;
+		const float w = k[i];
+		weight = in ? weight + w : weight;
+		total = in ? total + v[i] * w : total;
+	}
+	return total / weight;
+}
+template <int KW>
+__global__ __launch_bounds__(256) void k_blur_fused(ConvParams P) {
+	constexpr int R = KW / 2, NC = (R + 3) / 4, NL = 1 + 2 * NC, PL = 4 * NC;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;
+	constexpr int ROWS = BF_ROWS;
+	const int y0 = (blockIdx.y * 4 + wave) * ROWS;
+	if (x >= P.width || y0 >= P.height) return;
+	const int W = P.width, H = P.height;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride + x;
+	const int yEnd = min(y0 + ROWS, H);
+	const bool colsInterior = x >= R && x + 3 < W - R;     // all four columns are interior columns of the horizontal pass
+	const bool full4 = x + 3 < W;
+	const int yLast = min(yEnd + R, H);                    // input rows of the strip: [max(y0 - R, 0), yLast)
+	// the lane's chunk of a row and the chunks the kernel reaches into (neighbouring lanes' chunks: L1 hits)
+	auto fetch = [&](float4 (&buf)[NL], int yy) {
+		if (yy >= 0 && yy < yLast) {
+			const float* row = img + (long long)yy * P.inStride;
+#pragma unroll
+			for (int c = 0; c < NL; c++) buf[c] = loadRow4(row, x - PL + 4 * c, W);
+		}
+	};
+	// horizontal pass of one row for the lane's four columns: the value ConvolveImageNormalized.horizontal leaves in `storage`
+	auto hfilter = [&](const float4 (&buf)[NL]) -> float4 {
+		float v[4 * NL];
+#pragma unroll
+		for (int c = 0; c < NL; c++) { v[4 * c] = buf[c].x; v[4 * c + 1] = buf[c].y; v[4 * c + 2] = buf[c].z; v[4 * c + 3] = buf[c].w; }
+		float r[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			float t[KW];
+#pragma unroll
+			for (int i = 0; i < KW; i++) t[i] = v[PL - R + j + i];
+			if (colsInterior) r[j] = blurTapsInterior<KW>(t, P.k);
+			else r[j] = (x + j >= R && x + j < W - R) ? blurTapsInterior<KW>(t, P.k) : blurTapsBorder<KW>(t, P.k, x + j - R, W);
+		}
+		return make_float4(r[0], r[1], r[2], r[3]);
+	};
+	// ring[i] = horizontally filtered row (yy - 2R + i) once input row yy has been pushed: the KW taps of output row yy - R, in tap order.
+	// The ring is shifted by register moves (KW x 4 per row, against 16 KW multiply-adds), which keeps the row loop one small body.
+	float4 ring[KW];
+#pragma unroll
+	for (int i = 0; i < KW; i++) ring[i] = make_float4(0, 0, 0, 0);
+	float4 cur[NL], nxt[NL];   // two rows in flight ahead of the one being filtered
+#pragma unroll
+	for (int c = 0; c < NL; c++) { cur[c] = make_float4(0, 0, 0, 0); nxt[c] = make_float4(0, 0, 0, 0); }
+	fetch(cur, y0 - R);
+	fetch(nxt, y0 - R + 1);
+#pragma unroll 1
+	for (int yy = y0 - R; yy < yEnd + R; yy++) {
+		float4 hrow = make_float4(0, 0, 0, 0);
+		if (yy >= 0 && yy < H) hrow = hfilter(cur);   // rows outside the image are never used as taps (wave-uniform branch)
+#pragma unroll
+		for (int c = 0; c < NL; c++) cur[c] = nxt[c];
+		fetch(nxt, yy + 2);
+#pragma unroll
+		for (int i = 0; i + 1 < KW; i++) ring[i] = ring[i + 1];
+		ring[KW - 1] = hrow;
+		const int y = yy - R;   // the output row whose last tap just arrived
+		if (y >= y0) {
+			const bool rowInterior = y >= R && y < H - R;   // wave-uniform
+			float r[4];
+			if (rowInterior) {
+				// the four columns as two packed pairs (v_pk_mul_f32 / v_pk_add_f32): component-wise the reference's expression, half the instructions
+				typedef float f32x2 __attribute__((ext_vector_type(2)));
+				f32x2 lo = f32x2{ring[0].x, ring[0].y} * P.k[0], hi = f32x2{ring[0].z, ring[0].w} * P.k[0];
+#pragma unroll
+				for (int i = 1; i < KW; i++) {
+					lo += f32x2{ring[i].x, ring[i].y} * P.k[i];
+					hi += f32x2{ring[i].z, ring[i].w} * P.k[i];
+				}
+				r[0] = lo.x; r[1] = lo.y; r[2] = hi.x; r[3] = hi.y;
+			} else {
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					float tv[KW];
+#pragma unroll
+					for (int i = 0; i < KW; i++) tv[i] = q == 0 ? ring[i].x : q == 1 ? ring[i].y : q == 2 ? ring[i].z : ring[i].w;
+					r[q] = blurTapsBorder<KW>(tv, P.k, y - R, H);
+				}
+			}
+			float* dst = outImg + (long long)y * P.outStride;
+			if (full4) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+			else
+				for (int q = 0; q < 4 && x + q < W; q++) dst[q] = r[q];
+		}
+	}
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float* kernel, int kw, int koff, const float* in, int inStride, int width,
@@ -489,6 +612,49 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 #undef LAUNCH_H
 	}
 	BHIP_HIP(ctx, hipGetLastError());
+	return BHIP_OK;
+}
+
+// BlurImageOps.gaussian in one pass; returns *done = false when the shape / kernel is outside what the fused kernel covers (the caller
+// then runs the two separable passes)
+int bhip_launch_blur_fused(bhip_ctx* ctx, const float* kernel, int kw, const float* in, int inStride, int width, int height, float* out, int outStride, int batch,
+						   long long inImageStride, long long outImageStride, bool* done) {
+	*done = false;
+	if (width <= 0 || height <= 0 || batch <= 0) { *done = true; return BHIP_OK; }
+	const bool unrolled = kw == 3 || kw == 5 || kw == 7 || kw == 9 || kw == 11;
+	if (!unrolled || kw >= width || kw >= height) return BHIP_OK;   // standard-form widths and the naive form (kernel wider than the image)
+	if (!(aligned16(in) && aligned16(out) && inStride % 4 == 0 && outStride % 4 == 0 && inImageStride % 4 == 0 && outImageStride % 4 == 0)) return BHIP_OK;
+	if (bhip_env_flag("BHIP_BLUR_TWO_PASS")) return BHIP_OK;        // parity cross-check of the two forms
+	ConvParams P;
+	P.in = in; P.out = out; P.inStride = inStride; P.outStride = outStride; P.width = width; P.height = height; P.kw = kw; P.koff = kw / 2;
+	P.inImageStride = inImageStride; P.outImageStride = outImageStride;
+	for (int i = 0; i < kw; i++) P.k[i] = kernel[i];
+	P.unrolled = 1; P.mode = 1; P.borderOnly = 0;
+	{
+		// ConvolveImageNormalized: re-normalise when |sum - 1| > 1e-4 (both passes see the same kernel)
+		float sum = 0;
+		for (int i = 0; i < kw; i++) sum += P.k[i];
+		float diff = sum - 1.0f;
+		if (diff < 0) diff = -diff;
+		if (diff > 1e-4f) {
+			float total = 0;
+			for (int i = 0; i < kw; i++) total += P.k[i];
+			for (int i = 0; i < kw; i++) P.k[i] /= total;
+		}
+	}
+	// algorithmic bytes: the two separable passes of SURVEY 8d (8P each)
+	ProfScope prof(ctx, "k_blur_fused", 16.0 * width * height * batch);
+	const int rowsPerWave = BF_ROWS;
+	dim3 grid((width + 255) / 256, (height + 4 * rowsPerWave - 1) / (4 * rowsPerWave), batch);
+	switch (kw) {
+	case 3: hipLaunchKernelGGL(k_blur_fused<3>, grid, dim3(256), 0, ctx->stream, P); break;
+	case 5: hipLaunchKernelGGL(k_blur_fused<5>, grid, dim3(256), 0, ctx->stream, P); break;
+	case 7: hipLaunchKernelGGL(k_blur_fused<7>, grid, dim3(256), 0, ctx->stream, P); break;
+	case 9: hipLaunchKernelGGL(k_blur_fused<9>, grid, dim3(256), 0, ctx->stream, P); break;
+	default: hipLaunchKernelGGL(k_blur_fused<11>, grid, dim3(256), 0, ctx->stream, P); break;
+	}
+	BHIP_HIP(ctx, hipGetLastError());
+	*done = true;
 	return BHIP_OK;
 }
 

@@ -73,7 +73,7 @@ def main():
             emit("conv_norm_v r=%d" % r, run(ctx, lambda: ops.convolveNormalizedVertical(k, r, src, dst), 10))
             p = run(ctx, lambda: ops.gaussian(src, -1, r, dst), 10)
             ms = sum(v[0] for v in p.values()); nb = sum(v[1] for v in p.values())
-            emit("gaussian blur r=%d (both passes)" % r, {"k_conv_h+k_conv_v": (ms, nb)})
+            emit("gaussian blur r=%d (16P algorithmic: one-pass kernel for the unrolled widths, two passes otherwise)" % r, {"+".join(sorted(p)): (ms, nb)})
         emit("sobel", run(ctx, lambda: ops.sobel(src, 0, dst, dst2), 10))
         emit("three", run(ctx, lambda: ops.three(src, 0, dst, dst2), 10))
         k2 = api.FactoryKernelGaussian.gaussian1D_F32(-1, 2).data

@@ -474,6 +474,44 @@ def test_convolution_and_blur_bit_exact(api, orc):
     assert np.array_equal(bits(out.array()), bits(orc.conv("norm_h", orc.gaussian1d_f32(-1, 2), 2, img).array()))
 
 
+def test_one_pass_gaussian_blur_bit_exact(api, orc, monkeypatch):
+    """BlurImageOps.gaussian for the unrolled widths runs as ONE kernel (horizontal filter in registers, vertical filter from a register
+    ring): bit-exact against the oracle's two passes and against the library's own two-pass form (BHIP_BLUR_TWO_PASS=1) on shapes that
+    exercise every position class -- widths that are no multiple of 4 or of 256, strips shorter than the kernel reach, images barely larger
+    than the kernel, several strips per column, device batches"""
+    import torch
+    from boofcv_amd import device as dv
+    rand = orc.JavaRandom(77)
+    shapes = [(12, 12), (13, 70), (70, 13), (259, 40), (300, 131), (517, 65), (64, 200)]
+    for (w, h) in shapes:
+        img = rand.fillUniform(orc.Gray(w, h), 0, 255)
+        for radius in (1, 2, 3, 4, 5):
+            if 2 * radius + 1 >= min(w, h):
+                continue
+            ref = bits(orc.gaussian_blur(img, -1, radius).array())
+            out = api.BlurImageOps.gaussian(G(api, img), None, -1, radius)
+            assert np.array_equal(bits(out.array()), ref), (w, h, radius)
+            monkeypatch.setenv("BHIP_BLUR_TWO_PASS", "1")
+            out2 = api.BlurImageOps.gaussian(G(api, img), None, -1, radius)
+            monkeypatch.delenv("BHIP_BLUR_TWO_PASS")
+            assert np.array_equal(bits(out2.array()), ref), (w, h, radius, "two pass")
+    # a kernel whose fp32 sum is off by more than 1e-4 is re-normalised by both passes (sigma given, radius given)
+    img = rand.fillUniform(orc.Gray(90, 77), -20, 20)
+    for sigma, radius in [(3.0, 2), (0.7, 3), (5.0, 5)]:
+        out = api.BlurImageOps.gaussian(G(api, img), None, sigma, radius)
+        assert np.array_equal(bits(out.array()), bits(orc.gaussian_blur(img, sigma, radius).array())), (sigma, radius)
+    # device batch, on torch's stream: every image equals its single-image result
+    ctx = api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream)
+    ops = dv.DeviceImageOps(ctx)
+    imgs = [rand.fillUniform(orc.Gray(324, 100), 0, 100) for _ in range(3)]
+    t = torch.from_numpy(np.stack([g.array() for g in imgs])).to("cuda:0")
+    for radius in (2, 5):
+        got = ops.gaussian(t, -1, radius).cpu().numpy()
+        for i, g in enumerate(imgs):
+            assert np.array_equal(bits(got[i]), bits(orc.gaussian_blur(g, -1, radius).array())), (radius, i)
+    ctx.close()
+
+
 def test_gradients_bit_exact(api, orc):
     rand = orc.JavaRandom(234)
     for (w, h) in [(31, 26), (200, 100), (3, 3), (5, 4)]:
