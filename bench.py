@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-boundary (PCIe-inclusive) leg")
+    ap.add_argument("--end-to-end", action="store_true", help="run the host-boundary leg at --gpus > 1 too (default there: skipped, the scaling run stays short)")
+    ap.add_argument("--no-conv", action="store_true", help="skip the convolution front-end leg (Gaussian blur, Sobel, pyramid layer on 64 of the resident frames)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only report their environment; no GPU call anywhere (launcher test)")
     return ap.parse_args(argv)
 
@@ -381,6 +383,15 @@ class Dist:
     def ranks_seen(self):
         return self.dist.get_world_size() if self.dist is not None else 1
 
+    def device_ids(self):
+        """the device index every rank runs on, in rank order (one all-gather of one integer per rank)"""
+        if self.dist is None:
+            return [self.local_rank]
+        mine = self.torch.tensor([self.local_rank], dtype=self.torch.int64, device=self.ctl_device)
+        out = [self.torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [int(t.item()) for t in out]
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -463,7 +474,7 @@ def run_frames(args, D):
 
     # host-boundary leg (every rank runs it at the same time: the ranks share the host's PCIe complex and cores)
     e2e = None
-    if not args.no_end_to_end:
+    if not args.no_end_to_end and (D.world == 1 or args.end_to_end):
         host = torch.empty((B, H, W), dtype=torch.float32, pin_memory=True)
         host.copy_(frames)
         torch.cuda.synchronize()
@@ -501,6 +512,37 @@ def run_frames(args, D):
                "matches_per_frame": round(matches_strict / B, 1), "batched_calls": batched}
         del hb
 
+    # convolution front end on the same resident frames (north_star: ">= 60 % HBM roofline for convolution"): one short leg so that the
+    # driver's line carries it -- Gaussian blur r = 2 and r = 5 (one-pass kernel; 16P algorithmic bytes = the two separable passes of
+    # SURVEY 8d), Sobel (12P), the discrete pyramid's first down-sampling layer (4(P + P/2) + 4(P/2 + P/4))
+    conv = None
+    devices = D.device_ids()
+    if D.rank == 0 and not args.no_conv and D.world == 1:
+        from boofcv_amd import device as dv
+        ops = dv.DeviceImageOps(hp.ctx)
+        nb = min(B, 64)
+        src = frames[:nb]
+        dst = torch.empty_like(src); dst2 = torch.empty_like(src)
+        ker2 = hp.api.FactoryKernelGaussian.gaussian1D_F32(-1, 2).data
+        P = float(nb * H * W)
+        legs = [("gaussian_r2", lambda: ops.gaussian(src, -1, 2, dst), 16 * P), ("gaussian_r5", lambda: ops.gaussian(src, -1, 5, dst), 16 * P),
+                ("sobel", lambda: ops.sobel(src, 0, dst, dst2), 12 * P), ("pyramid_1_2", lambda: ops.pyramid(ker2, [1, 2], src), None)]
+        conv = {"batch": "%dx%dx%d" % (nb, W, H), "peak_GBs": HBM_PEAK_GBS}
+        for name, fn, alg in legs:
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            hp.ctx.profile(True); hp.ctx.profileReset()
+            reps = 5
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            pr = hp.ctx.profileReport(); hp.ctx.profile(False)
+            ms = sum(v["ms"] for v in pr.values()) / reps
+            nbytes = alg if alg is not None else sum(v["bytes"] for v in pr.values()) / reps
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            conv[name] = {"ms": round(ms, 4), "GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 3), "kernels": sorted(pr)}
+        del dst, dst2
     if D.rank != 0:
         return None
     frames_total = D.world * B * steps
@@ -553,8 +595,8 @@ def run_frames(args, D):
         "dtype": "f32 detect / f64 describe / associate: fp16 MFMA candidate filter + exact fp64 re-score", "data": "synthetic",
         "config": {"workload": "batch of %d %dx%d GrayF32 per GPU: Fast-Hessian detect + SURF-64 (stable) describe + greedy L2 associate with the next frame"
                                % (B, W, H), "batch_per_gpu": B, "width": W, "height": H, "keypoints_per_frame": round(kp_all / (D.world * B), 1),
-                   "ranks_seen": D.ranks_seen()},
-        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
+                   "ranks_seen": D.ranks_seen(), "device_ids": devices},
+        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "conv": conv,
     }
 
 

@@ -1354,6 +1354,28 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 				{ ProfScope p2(ctx, "k_describe_desc"); BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, ad, ldsBytes, ctx->stream)); }
 				return BHIP_OK;
 			}
+			if (e && e[0] == '2' && P.angles && P.desc && !P.anglesIn) {
+				// experiment: both halves at the same time on two streams (the descriptor half reads the angles the previous call left in the
+				// buffer: timing only, results are stale) -- how much of the fused kernel's time is lost to the two halves not overlapping?
+				static hipStream_t side = nullptr;
+				static hipEvent_t evFork = nullptr, evJoin = nullptr;
+				if (!side) { (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking); (void)hipEventCreateWithFlags(&evFork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&evJoin, hipEventDisableTiming); }
+				DescParams Po = P, Pd = P;
+				Po.desc = nullptr; Po.white = nullptr;
+				static double* staleAngles = nullptr; static long long staleN = 0;
+				if (staleN < P.total) { if (staleAngles) (void)hipFree(staleAngles); (void)hipMalloc(&staleAngles, (size_t)P.total * 8); (void)hipMemsetAsync(staleAngles, 0, (size_t)P.total * 8, ctx->stream); staleN = P.total; }
+				Pd.anglesIn = staleAngles; Pd.angles = nullptr;
+				void* ao[] = {(void*)&Po};
+				void* ad[] = {(void*)&Pd};
+				BHIP_HIP(ctx, hipEventRecord(evFork, ctx->stream));
+				BHIP_HIP(ctx, hipStreamWaitEvent(side, evFork, 0));
+				BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, ad, ldsBytes, side));
+				BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, ao, ldsBytes, ctx->stream));
+				BHIP_HIP(ctx, hipEventRecord(evJoin, side));
+				BHIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, evJoin, 0));
+				BHIP_HIP(ctx, hipMemcpyAsync(staleAngles, P.angles, (size_t)P.total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+				return BHIP_OK;
+			}
 		}
 #endif
 		BHIP_HIP(ctx, hipLaunchKernel(fn, grid, block, args, ldsBytes, ctx->stream));

@@ -10,7 +10,8 @@ rebuilt.  Parity with Java rests on the reference's own known-answer literals (t
 
 Inputs are regenerated from the seeds (ImageMiscOps.fillUniform with java.util.Random, restated in oracle/), so only outputs are stored:
 key points (x, y, scale: float64, exact), orientation, Laplacian sign, descriptors as float32 (the parity bar is 1e-5), association
-pairs and fit scores, and BRIEF-512 words at the first 64 key points.
+pairs and fit scores, BRIEF-512 words at the first 64 key points, and -- for an exact association check -- every 8th descriptor of both
+frames as float64 together with the association of those two subsets.
 
     python tests/golden/make_golden.py          # rewrites the fixture (review the diff!)
 """
@@ -50,6 +51,12 @@ def generate(width=W, height=H, desc_every=1):
     pairs, fit = orc.associate_l2(descs[0], descs[1], backwards=True)
     out["pairs"] = pairs
     out["fit"] = fit
+    # An association whose inputs are stored exactly: every 8th descriptor of both frames as float64, and the oracle's greedy mutual-best
+    # association of those two subsets.  A GPU association of these stored inputs must reproduce pairs64 / fit64 bit for bit (the full-set
+    # comparison above goes through the GPU's own descriptors, which differ from the oracle's in the last bits).
+    out["desc64_0"] = np.ascontiguousarray(descs[0][::8])
+    out["desc64_1"] = np.ascontiguousarray(descs[1][::8])
+    out["pairs64"], out["fit64"] = orc.associate_l2(out["desc64_0"], out["desc64_1"], backwards=True)
     return out
 
 
