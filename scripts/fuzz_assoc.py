@@ -24,9 +24,12 @@ def greedy(score, maxErr, backwards, src, dst):
     return alg.getPairs(), alg.getFitQuality()
 
 
-def main():
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+def main(seed=None, cases=None):
+    """seed / cases default to the command line (tests/test_gpu_fuzz_slice.py runs a bounded slice in-process)"""
+    if seed is None:
+        seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    if cases is None:
+        cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     rng = np.random.default_rng(seed)
     orc.build()
     bad = 0

@@ -33,9 +33,12 @@ def frame(rng, w, h, kind):
     return (a + rng.uniform(0, 2, (h, w))).astype(np.float32)
 
 
-def main():
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+def main(seed=None, cases=None):
+    """seed / cases default to the command line (tests/test_gpu_fuzz_slice.py runs a bounded slice in-process)"""
+    if seed is None:
+        seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    if cases is None:
+        cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
     rng = np.random.default_rng(seed)
     orc.build()
     bad = 0

@@ -3,11 +3,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export BHIP_LIB=$GRAFT_REPO_ROOT/boofcv_amd/libboofhip_exp.so
 export BHIP_BENCH_FRAMES_CACHE=/tmp/bhip_frames
-python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > /dev/null 2>&1
+python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --no-conv --batch 32 > /dev/null 2>&1
 rm -rf gpurun_out/pmc_fphase && mkdir -p gpurun_out/pmc_fphase
 for ab in 0 1 2 4 7; do
   export BHIP_FUSED_ABLATE=$ab
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_fphase/a$ab -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > gpurun_out/pmc_fphase/run$ab.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_fphase/a$ab -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --no-conv --batch 32 > gpurun_out/pmc_fphase/run$ab.log 2>&1
   python3 - $ab >> gpurun_out/pmc_fphase/summary.txt <<'PY'
 import csv, glob, collections, sys
 ab = sys.argv[1]

@@ -1,11 +1,11 @@
 # texture-addresser / L1 pressure of the gather kernels (rocprofv3 PMC, batch 32): TA busy share, requests per wave, stalls
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export BHIP_BENCH_FRAMES_CACHE=/tmp/bhip_frames
-python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > /dev/null 2>&1
+python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --no-conv --batch 32 > /dev/null 2>&1
 rm -rf gpurun_out/pmc_ta && mkdir -p gpurun_out/pmc_ta
 for set in "TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"; do
   tag=$(echo $set | cut -d' ' -f1)
-  timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_ta/$tag -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --batch 32 > gpurun_out/pmc_ta/$tag.log 2>&1 || echo "pass $tag failed"
+  timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_ta/$tag -- python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --no-conv --batch 32 > gpurun_out/pmc_ta/$tag.log 2>&1 || echo "pass $tag failed"
 done
 python3 - <<'PY'
 import csv, glob, collections

@@ -3,11 +3,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # synthetic frames are generated once outside the profiler (bench.py BHIP_BENCH_FRAMES_CACHE) and re-read by the profiled runs
 export BHIP_BENCH_FRAMES_CACHE=/tmp/bhip_frames
-python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end > /dev/null 2>&1
+python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-end-to-end --no-conv > /dev/null 2>&1
 rm -rf gpurun_out/pmc_traffic && mkdir -p gpurun_out/pmc_traffic
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc pass $c: $(date +%T)"
-  BHIP_BENCH_TRACE=1 timeout -k 10 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic/$c -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-end-to-end > gpurun_out/pmc_traffic/$c.log 2>&1 || exit 1
+  BHIP_BENCH_TRACE=1 timeout -k 10 180 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_traffic/$c -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-end-to-end --no-conv > gpurun_out/pmc_traffic/$c.log 2>&1 || exit 1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
