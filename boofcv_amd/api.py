@@ -98,10 +98,10 @@ class Context:
             _lib.load().bhip_ctx_destroy(self._h)
             self._h = None
 
-    def __del__(self):
-        if sys.is_finalizing():
-            return   # the atexit hook below has closed what was alive; the native library ignores destroy calls after exit began
+    def __del__(self, _finalizing=sys.is_finalizing):   # (bound at definition: module globals are gone when this runs late in shutdown)
         try:
+            if _finalizing():
+                return   # the atexit hook below has closed what was alive; the native library ignores destroy calls after exit began
             self.close()
         except Exception:
             pass
@@ -443,10 +443,10 @@ class DetectDescribePoint:
             _lib.load().bhip_surf_destroy(self._h)
             self._h = None
 
-    def __del__(self):
-        if sys.is_finalizing():
-            return
+    def __del__(self, _finalizing=sys.is_finalizing):
         try:
+            if _finalizing():
+                return
             self.close()
         except Exception:
             pass

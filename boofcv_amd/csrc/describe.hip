@@ -96,8 +96,9 @@ struct TapBases {
 // every lane of the wave holds the same value (one key point per wave): move it to a scalar register, so that what is derived from it
 // (tap bases, bounds) stays scalar too
 __device__ __forceinline__ unsigned int uniformU32(unsigned int v) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)v); }
+// safe8: any 8 readable bytes (the pair loads of an image smaller than the kernel go there; their value is never used)
 template <class T>
-__device__ __forceinline__ TapBases<T> makeBases(const T* d, int r, int stride, int W, int H) {
+__device__ __forceinline__ TapBases<T> makeBases(const T* d, int r, int stride, int W, int H, const void* safe8) {
 	TapBases<T> B;
 	r = (int)uniformU32((unsigned)r);   // (the image base d is uniform already: kernel argument + uniform image index)
 	B.anyInside = (2 * r + 2 <= W) && (2 * r + 2 <= H);
@@ -107,10 +108,10 @@ __device__ __forceinline__ TapBases<T> makeBases(const T* d, int r, int stride, 
 	const T* c1 = a + rr * st;
 	const T* c2 = c1 + st;
 	const T* b = c2 + rr * st;
-	B.a0 = (const char*)a; B.a1 = (const char*)(a + rr); B.a3 = (const char*)(a + w);
+	B.a0 = (const char*)a; B.a1 = B.anyInside ? (const char*)(a + rr) : (const char*)safe8; B.a3 = (const char*)(a + w);
 	B.c10 = (const char*)c1; B.c13 = (const char*)(c1 + w);
 	B.c20 = (const char*)c2; B.c23 = (const char*)(c2 + w);
-	B.b0 = (const char*)b; B.b1 = (const char*)(b + rr); B.b3 = (const char*)(b + w);
+	B.b0 = (const char*)b; B.b1 = B.anyInside ? (const char*)(b + rr) : (const char*)safe8; B.b3 = (const char*)(b + w);
 	B.r1 = (unsigned)(r + 1);
 	B.spanX = B.anyInside ? (unsigned)(W - 2 * r - 1) : 0u;
 	B.spanY = B.anyInside ? (unsigned)(H - 2 * r - 1) : 0u;
@@ -135,19 +136,23 @@ __device__ __forceinline__ void gradFetch(const TapBases<T>& B, int x, int y, bo
 	// is an addressing mode of global_load; if the compiler is left to fold the select into a 64-bit offset it adds base and offset per tap
 	// (buffer loads with the distances as scalar offsets measured 9 % slower than this form, with or without the sc0 policy)
 	asm volatile("" : "+v"(off));
-	t.p0 = tapAt<T>(B.a0, off); t.p3 = tapAt<T>(B.a3, off);
+	// The accesses are issued row by row (top row: left, centre pair, right; the two middle rows; bottom row): the taps of one row often
+	// share a 128-byte line, and with 16 waves of different key points streaming through a CU's 32 KB L1 a line survives a few instructions,
+	// not a whole sample.  The two centre columns of the top and of the bottom row are neighbours: one 8-byte request each instead of
+	// two 4-byte ones.
+	t.p0 = tapAt<T>(B.a0, off);
+	const Pair2<T> a = *(const Pair2<T>*)(B.a1 + off);
+	t.p1 = a.x; t.p2 = a.y;
+	t.p3 = tapAt<T>(B.a3, off);
+	__builtin_amdgcn_sched_barrier(0);   // keep the issue order row by row (the loads are independent: the scheduler would group them by width)
 	t.p11 = tapAt<T>(B.c10, off); t.p4 = tapAt<T>(B.c13, off);
+	__builtin_amdgcn_sched_barrier(0);
 	t.p10 = tapAt<T>(B.c20, off); t.p5 = tapAt<T>(B.c23, off);
-	t.p9 = tapAt<T>(B.b0, off); t.p6 = tapAt<T>(B.b3, off);
-	if (B.anyInside) {
-		// the two centre columns of the top and of the bottom row are neighbours: one 8-byte request each instead of two 4-byte ones
-		// (the texture addresser is this kernel's co-limiter and works per lane access, not per byte)
-		const Pair2<T> a = *(const Pair2<T>*)(B.a1 + off), b = *(const Pair2<T>*)(B.b1 + off);
-		t.p1 = a.x; t.p2 = a.y;
-		t.p8 = b.x; t.p7 = b.y;
-	} else {
-		t.p1 = t.p0; t.p2 = t.p0; t.p8 = t.p0; t.p7 = t.p0;
-	}
+	__builtin_amdgcn_sched_barrier(0);
+	t.p9 = tapAt<T>(B.b0, off);
+	const Pair2<T> b = *(const Pair2<T>*)(B.b1 + off);
+	t.p8 = b.x; t.p7 = b.y;
+	t.p6 = tapAt<T>(B.b3, off);
 	t.inb = inb;
 }
 template <class T>
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	} else {
 		const double radius = kp.scale * P.oriRadiusFactor;
 		const double oscale = radius * T.oriRadiusToScale;    // setObjectRadius
-		const TapBases<TAP> G = makeBases<TAP>(d, gradRadius(oscale * T.oriKernelWidth), stride, W, H);
+		const TapBases<TAP> G = makeBases<TAP>(d, gradRadius(oscale * T.oriKernelWidth), stride, W, H, P.kps);
 		const double period = oscale * T.oriPeriod;
 		double tl_x = kp.x - T.oriRadius * period;
 		double tl_y = kp.y - T.oriRadius * period;
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	for (int band = 0; band < nb; band++) {
 	const TAP* __restrict__ db = P.nBands > 0 ? (const TAP*)P.bandData + (long long)img * P.bandImageStride + (long long)band * P.bandStride : d;
 	if (band > 0) waveSync();   // the previous band's sums have read sX, sY
-	const TapBases<TAP> G = makeBases<TAP>(db, descR, stride, W, H);
+	const TapBases<TAP> G = makeBases<TAP>(db, descR, stride, W, H, P.kps);
 	{
 		// sample grid in 8x8 blocks: the 64 lanes of one pass cover a compact (8 scale)^2 patch of the image, so a wave-level gather
 		// touches a few dozen cache lines instead of up to 64.  The LDS layout stays [iy][ix].
