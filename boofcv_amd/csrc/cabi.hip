@@ -1632,9 +1632,13 @@ int bhip_pyramid_dev_f32(bhip_ctx* ctx, const float* kernel, int kw, const int* 
 		} else {
 			const int skip = i == 0 ? scales[0] : scales[i] / scales[i - 1];
 			const int tw = pw / skip;   // 0 when the layer below is narrower than the step: both passes then write nothing and the (ceil-sized) layer stays zero, as in the reference
-			BHIP_TRY(bhip_launch_conv_down(ctx, false, kernel, kw, prev, prevImageStride, prevStride, pw, ph, sc->d.as<float>(), tempCap, tw, tw, ph, skip,
-										   batch));
-			BHIP_TRY(bhip_launch_conv_down(ctx, true, kernel, kw, sc->d.as<float>(), tempCap, tw, tw, ph, layer, total, lw, lw, lh, skip, batch));
+			bool fused = false;
+			BHIP_TRY(bhip_launch_pyr_layer_fused(ctx, kernel, kw, prev, prevImageStride, prevStride, pw, ph, layer, total, lw, skip, batch, &fused));
+			if (!fused) {
+				BHIP_TRY(bhip_launch_conv_down(ctx, false, kernel, kw, prev, prevImageStride, prevStride, pw, ph, sc->d.as<float>(), tempCap, tw, tw, ph, skip,
+											   batch));
+				BHIP_TRY(bhip_launch_conv_down(ctx, true, kernel, kw, sc->d.as<float>(), tempCap, tw, tw, ph, layer, total, lw, lw, lh, skip, batch));
+			}
 		}
 		prev = layer; prevImageStride = total; prevStride = lw; pw = lw; ph = lh;
 	}

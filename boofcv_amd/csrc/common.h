@@ -217,6 +217,8 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 					 int height, float* out, int outStride, int batch = 1, long long inImageStride = 0, long long outImageStride = 0);
 int bhip_launch_blur_fused(bhip_ctx* ctx, const float* kernel, int kw, const float* in, int inStride, int width, int height, float* out, int outStride, int batch,
 						   long long inImageStride, long long outImageStride, bool* done);
+int bhip_launch_pyr_layer_fused(bhip_ctx* ctx, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width, int height,
+								float* out, long long outImageStride, int outStride, int skip, int batch, bool* done);
 int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width,
 						  int height, float* out, long long outImageStride, int outStride, int outWidth, int outHeight, int skip, int batch);
 int bhip_launch_planar_average(bhip_ctx* ctx, const float* bands, long long bandStride, int numBands, long long n, float* out);

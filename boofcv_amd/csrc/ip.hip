@@ -932,6 +932,104 @@ int bhip_launch_conv_down(bhip_ctx* ctx, bool vertical, const float* kernel, int
 	return BHIP_OK;
 }
 
+// ---- one pyramid layer in ONE pass: PyramidDiscreteSampleBlur.process's horizontal.process(prev, temp); vertical.process(temp, layer)
+// (I:alg/transform/pyramid/PyramidDiscreteSampleBlur.java:88-118) for the usual step -- skip 2, widths 3 / 5.  Same scheme as
+// k_blur_fused: a wave owns 256 input columns (128 outputs) x PL_ROWS output rows, walks the input rows once, forms the horizontally
+// down-convolved row in registers (the value the reference leaves in `temp`: lane = input columns 4l..4l+3 = outputs 2l, 2l+1) and
+// feeds a register ring from which every second input row yields one output row.  `temp` never exists: 4 P_in read + P_in written
+// (+ 2R re-read rows per strip) instead of 4(P + P/2) + 4(P/2 + P/4).  Position classes per axis as in k_conv_down (skip 2: left border
+// = output 0, right border = outputs centred in [offsetEnd, sideTrunc), interior between; every output of the layer is written).
+#define PL_ROWS 16
+struct PyrLayerParams {
+	const float* in; float* out;
+	long long inImageStride, outImageStride;
+	int inStride, outStride, width, height;   // input size; outputs: width/2 x height/2
+	int offsetX, maxSideX, offsetEndX, sideTruncX;
+	int offsetY, maxSideY, offsetEndY, sideTruncY;
+	float k[16];
+};
+// 0 = interior, 1 = border (normalised over the taps inside the image), -1 = not an output of this layer
+__device__ __forceinline__ int pyrClass(int D, int outSide, int offset, int maxSide, int offsetEnd, int sideTrunc) {
+	if (D >= outSide) return -1;
+	const int centre = 2 * D;
+	if (centre >= offsetEnd && centre < sideTrunc) return 1;
+	if (centre < offset) return 1;
+	return centre <= maxSide ? 0 : -1;
+}
+template <int KW>
+__global__ __launch_bounds__(256) void k_pyr_layer_fused(PyrLayerParams P) {
+	constexpr int R = KW / 2;   // <= 2: the kernel reaches at most two columns into the neighbouring chunks
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = blockIdx.x * 256 + 4 * lane;          // first input column of this lane
+	const int W = P.width, H = P.height, outW = W / 2, outH = H / 2;
+	const int o0 = (blockIdx.y * 4 + wave) * PL_ROWS;
+	if (x >= W || o0 >= outH) return;
+	const float* img = P.in + (long long)blockIdx.z * P.inImageStride;
+	float* outImg = P.out + (long long)blockIdx.z * P.outImageStride;
+	const int oEnd = min(o0 + PL_ROWS, outH);
+	const int D0 = x >> 1;
+	const int c0 = pyrClass(D0, outW, P.offsetX, P.maxSideX, P.offsetEndX, P.sideTruncX), c1 = pyrClass(D0 + 1, outW, P.offsetX, P.maxSideX, P.offsetEndX, P.sideTruncX);
+	const int yFirst = 2 * o0 - R, yLast = min(2 * (oEnd - 1) + R, H - 1);   // input rows of the strip (clipped below when read)
+	auto fetch = [&](float4 (&buf)[3], int yy) {
+		if (yy >= 0 && yy <= yLast) {
+			const float* row = img + (long long)yy * P.inStride;
+#pragma unroll
+			for (int c = 0; c < 3; c++) buf[c] = loadRow4(row, x - 4 + 4 * c, W);
+		}
+	};
+	// the two outputs of this lane in one input row: what ConvolveImageDownNormalized.horizontal leaves in `temp`
+	auto hdown = [&](const float4 (&buf)[3]) -> float2 {
+		const float v[12] = {buf[0].x, buf[0].y, buf[0].z, buf[0].w, buf[1].x, buf[1].y, buf[1].z, buf[1].w, buf[2].x, buf[2].y, buf[2].z, buf[2].w};
+		float r[2];
+#pragma unroll
+		for (int j = 0; j < 2; j++) {
+			float t[KW];
+#pragma unroll
+			for (int i = 0; i < KW; i++) t[i] = v[4 + 2 * j - R + i];   // centre = input column x + 2 j = v[4 + 2 j]
+			const int cls = j == 0 ? c0 : c1;
+			r[j] = cls == 0 ? blurTapsInterior<KW>(t, P.k) : blurTapsBorder<KW>(t, P.k, x + 2 * j - R, W);
+		}
+		return make_float2(r[0], r[1]);
+	};
+	float2 ring[KW];   // ring[i] = `temp` row (yy - 2R + i) once input row yy has been pushed
+#pragma unroll
+	for (int i = 0; i < KW; i++) ring[i] = make_float2(0, 0);
+	float4 cur[3], nxt[3];
+#pragma unroll
+	for (int c = 0; c < 3; c++) { cur[c] = make_float4(0, 0, 0, 0); nxt[c] = make_float4(0, 0, 0, 0); }
+	fetch(cur, yFirst);
+	fetch(nxt, yFirst + 1);
+#pragma unroll 1
+	for (int yy = yFirst; yy <= 2 * (oEnd - 1) + R; yy++) {
+		float2 hrow = make_float2(0, 0);
+		if (yy >= 0 && yy < H) hrow = hdown(cur);
+#pragma unroll
+		for (int c = 0; c < 3; c++) cur[c] = nxt[c];
+		fetch(nxt, yy + 2);
+#pragma unroll
+		for (int i = 0; i + 1 < KW; i++) ring[i] = ring[i + 1];
+		ring[KW - 1] = hrow;
+		const int cy = yy - R;                   // centre row of the window now in the ring
+		if (cy >= 2 * o0 && (cy & 1) == 0) {
+			const int o = cy >> 1;
+			const int cls = pyrClass(o, outH, P.offsetY, P.maxSideY, P.offsetEndY, P.sideTruncY);   // wave-uniform
+			if (cls >= 0) {
+				float r[2];
+#pragma unroll
+				for (int q = 0; q < 2; q++) {
+					float tv[KW];
+#pragma unroll
+					for (int i = 0; i < KW; i++) tv[i] = q == 0 ? ring[i].x : ring[i].y;
+					r[q] = cls == 0 ? blurTapsInterior<KW>(tv, P.k) : blurTapsBorder<KW>(tv, P.k, cy - R, H);
+				}
+				float* dst = outImg + (long long)o * P.outStride + D0;
+				if (c0 >= 0 && c1 >= 0) *reinterpret_cast<float2*>(dst) = make_float2(r[0], r[1]);
+				else { if (c0 >= 0) dst[0] = r[0]; if (c1 >= 0) dst[1] = r[1]; }
+			}
+		}
+	}
+}
+
 // ---------------- batched image copy (pyramid layer 0 at scale 1: ImagePyramidBase keeps a copy of the input) ----------------
 __global__ __launch_bounds__(256) void k_copy_images(const float* __restrict__ in, long long inImageStride, int inStride, float* __restrict__ out,
 													   long long outImageStride, int outStride, int width, int height, int vec) {
@@ -947,6 +1045,46 @@ __global__ __launch_bounds__(256) void k_copy_images(const float* __restrict__ i
 			for (int q = 0; q < 4 && x + q < width; q++) d[q] = s[q];
 	}
 }
+// *done = false: the shape / kernel is outside what the fused layer kernel covers (the caller runs the two passes through `temp`)
+int bhip_launch_pyr_layer_fused(bhip_ctx* ctx, const float* kernel, int kw, const float* in, long long inImageStride, int inStride, int width, int height,
+								float* out, long long outImageStride, int outStride, int skip, int batch, bool* done) {
+	*done = false;
+	if (skip != 2 || !(kw == 3 || kw == 5) || batch <= 0) return BHIP_OK;
+	const int r = kw / 2;
+	if (kw >= width / 2 || kw >= height) return BHIP_OK;        // naive forms (the reference's vertical pass tests the width of `temp`, width / 2)
+	if (width / 2 <= 0 || height / 2 <= 0) return BHIP_OK;
+	if (!(aligned16(in) && inStride % 4 == 0 && inImageStride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && outStride % 2 == 0 && outImageStride % 2 == 0))
+		return BHIP_OK;
+	if (bhip_env_flag("BHIP_PYRAMID_TWO_PASS")) return BHIP_OK;  // parity cross-check of the two forms
+	PyrLayerParams P;
+	P.in = in; P.out = out; P.inImageStride = inImageStride; P.outImageStride = outImageStride; P.inStride = inStride; P.outStride = outStride;
+	P.width = width; P.height = height;
+	for (int i = 0; i < kw; i++) P.k[i] = kernel[i];
+	for (int axis = 0; axis < 2; axis++) {
+		const int side = axis == 0 ? width : height;
+		const int offset = downOffset(2, r), maxSide = downMaxSide(side, 2, r), offsetEnd = maxSide + 2, sideTrunc = side - side % 2;
+		if (offset % 2 != 0) return BHIP_OK;
+		// the same fit checks bhip_launch_conv_down makes (a shape it rejects must be rejected there, with its message)
+		bool ok = true;
+		if (offset <= maxSide) ok = ok && offset - r >= 0;
+		const int lastLeft = ((offset - 1) / 2) * 2;
+		ok = ok && lastLeft + r < side;
+		if (offsetEnd < sideTrunc) ok = ok && offsetEnd - r >= 0;
+		if (!ok) return BHIP_OK;
+		if (axis == 0) { P.offsetX = offset; P.maxSideX = maxSide; P.offsetEndX = offsetEnd; P.sideTruncX = sideTrunc; }
+		else { P.offsetY = offset; P.maxSideY = maxSide; P.offsetEndY = offsetEnd; P.sideTruncY = sideTrunc; }
+	}
+	// algorithmic bytes: the two passes of SURVEY 8d, 4 (P_in + P_out) each
+	const double Pin = (double)width * height, Ptmp = (double)(width / 2) * height, Pout = (double)(width / 2) * (height / 2);
+	ProfScope prof(ctx, "k_pyr_layer_fused", 4.0 * batch * ((Pin + Ptmp) + (Ptmp + Pout)));
+	dim3 grid((width + 255) / 256, (height / 2 + 4 * PL_ROWS - 1) / (4 * PL_ROWS), batch);
+	if (kw == 3) hipLaunchKernelGGL(k_pyr_layer_fused<3>, grid, dim3(256), 0, ctx->stream, P);
+	else hipLaunchKernelGGL(k_pyr_layer_fused<5>, grid, dim3(256), 0, ctx->stream, P);
+	BHIP_HIP(ctx, hipGetLastError());
+	*done = true;
+	return BHIP_OK;
+}
+
 int bhip_launch_copy_images(bhip_ctx* ctx, const float* in, long long inImageStride, int inStride, float* out, long long outImageStride, int outStride,
 							int width, int height, int batch) {
 	if (width <= 0 || height <= 0 || batch <= 0) return BHIP_OK;

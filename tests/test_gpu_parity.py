@@ -512,6 +512,43 @@ def test_one_pass_gaussian_blur_bit_exact(api, orc, monkeypatch):
     ctx.close()
 
 
+def test_one_pass_pyramid_layer_bit_exact(api, orc, monkeypatch):
+    """PyramidDiscreteSampleBlur's layer step (skip 2, widths 3 / 5) runs as ONE kernel per layer: bit-exact against the oracle's two passes
+    through `temp` and against the library's own two-pass form (BHIP_PYRAMID_TWO_PASS=1) -- even and odd sizes (the last output column /
+    row is a border output or does not exist), sizes barely above the kernel, several layers, device batches"""
+    import torch
+    from boofcv_amd import device as dv
+    rand = orc.JavaRandom(91)
+    for (w, h) in [(64, 48), (66, 50), (65, 49), (131, 77), (260, 38), (16, 16), (20, 12), (517, 130)]:
+        img = rand.fillUniform(orc.Gray(w, h), 0, 200)
+        for radius in (1, 2):
+            ker = orc.gaussian1d_f32(-1, radius)
+            for scales in ([2], [1, 2], [1, 2, 4], [2, 4, 8]):
+                try:
+                    exp, _ = orc.pyramid(ker, -1, scales, img)
+                except ValueError:
+                    continue   # a shape the reference rejects (covered by the acceptance tests)
+                for two_pass in (False, True):
+                    if two_pass:
+                        monkeypatch.setenv("BHIP_PYRAMID_TWO_PASS", "1")
+                    pyr = api.PyramidDiscreteSampleBlur(api.Kernel1D_F32(ker), -1, False, scales).process(G(api, img))
+                    if two_pass:
+                        monkeypatch.delenv("BHIP_PYRAMID_TWO_PASS")
+                    for i, e in enumerate(exp):
+                        assert np.array_equal(bits(pyr.getLayer(i).array()), bits(e)), (w, h, radius, scales, i, two_pass)
+    ctx = api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream)
+    ops = dv.DeviceImageOps(ctx)
+    imgs = [rand.fillUniform(orc.Gray(328, 122), 0, 100) for _ in range(3)]
+    t = torch.from_numpy(np.stack([g.array() for g in imgs])).to("cuda:0")
+    ker = orc.gaussian1d_f32(-1, 2)
+    layers = ops.pyramid(ker, [1, 2, 4], t)
+    for b, g in enumerate(imgs):
+        exp, _ = orc.pyramid(ker, -1, [1, 2, 4], g)
+        for i, e in enumerate(exp):
+            assert np.array_equal(bits(layers[i][b].cpu().numpy()), bits(e)), (b, i)
+    ctx.close()
+
+
 def test_gradients_bit_exact(api, orc):
     rand = orc.JavaRandom(234)
     for (w, h) in [(31, 26), (200, 100), (3, 3), (5, 4)]:
