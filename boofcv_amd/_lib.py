@@ -58,6 +58,7 @@ SIGNATURES = {
     "bhip_surf_detect_u8": (_i, [_vp, P(_u8p), _ip, _ip, _i, _i, _i]),
     "bhip_surf_detect_planar_f32": (_i, [_vp, P(_fp), _i, _i, _i, _i, _i]),
     "bhip_surf_count": (_i, [_vp, _i, _ip]),
+    "bhip_surf_counts": (_i, [_vp, _ip, _i]),
     "bhip_surf_fetch": (_i, [_vp, _i, _dp, _dp, _u8p, _dp]),
     "bhip_surf_fetch_all": (_i, [_vp, _dp, _dp, _u8p, _dp]),
     "bhip_assoc_l2_surf": (_i, [_vp, _i, _ip, _ip, _d, _i, _ip, _dp]),

@@ -522,11 +522,7 @@ class DetectDescribePoint:
         (e.g. views of page-locked memory a caller keeps across batches -- the copies then run at PCIe speed); views of the first `total`
         rows are returned."""
         L = _lib.load()
-        counts = np.zeros(self._batch, dtype=np.int32)
-        n = C.c_int(0)
-        for i in range(self._batch):
-            _check(self.ctx, L.bhip_surf_count(self._h, i, C.byref(n)))
-            counts[i] = n.value
+        counts = self.counts()
         starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         total = int(starts[-1])
         if out is None:
@@ -557,6 +553,13 @@ class DetectDescribePoint:
         _check(self.ctx, L.bhip_assoc_l2_surf(self._h, len(a), a.ctypes.data_as(_lib._ip), b.ctypes.data_as(_lib._ip), float(maxError),
                                               1 if backwardsValidation else 0, pairs.ctypes.data_as(_lib._ip), fit.ctypes.data_as(_lib._dp)))
         return pairs, fit
+
+    def counts(self):
+        """getNumberOfFeatures() of every image of the last batch (one native call) -> int32 array"""
+        out = np.zeros(max(self._batch, 1), dtype=np.int32)
+        if self._batch:
+            _check(self.ctx, _lib.load().bhip_surf_counts(self._h, out.ctypes.data_as(_lib._ip), len(out)))
+        return out[:self._batch]
 
     def totalFeatures(self):
         n = C.c_longlong(0)
@@ -841,11 +844,7 @@ class DetectDescribeFusion(DetectDescribePoint):
     def fetchAll(self, out=None):
         """(xy_scale [total,3], words [total, ceil(numPoints/32)] int32, starts [batch+1]) of the whole last batch."""
         L = _lib.load()
-        counts = np.zeros(self._batch, dtype=np.int32)
-        n = C.c_int(0)
-        for i in range(self._batch):
-            _check(self.ctx, L.bhip_surf_count(self._h, i, C.byref(n)))
-            counts[i] = n.value
+        counts = self.counts()
         starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         total = int(starts[-1])
         xys = np.empty((total, 3)); words = np.empty((total, self._words), dtype=np.int32)

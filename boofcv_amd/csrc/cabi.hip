@@ -891,6 +891,13 @@ int bhip_surf_count(bhip_surf* s, int image, int* n) {
 	*n = s->det.counts[image];
 	return BHIP_OK;
 }
+// getNumberOfFeatures() of every image of the last detect in one call (a batch-level caller's prefix sums)
+int bhip_surf_counts(bhip_surf* s, int* counts, int capacity) {
+	if (!s || !counts) return BHIP_ERR_INVALID;
+	if (!s->haveResult || capacity < s->batch) return bhip_fail(s->ctx, BHIP_ERR_INVALID, "no detect result / counts array too short");
+	for (int i = 0; i < s->batch; i++) counts[i] = s->det.counts[i];
+	return BHIP_OK;
+}
 int bhip_surf_total(bhip_surf* s, long long* n) {
 	if (!s || !n) return BHIP_ERR_INVALID;
 	*n = s->haveResult ? s->det.total : 0;

@@ -126,6 +126,8 @@ int bhip_surf_detect_u8(bhip_surf* s, const uint8_t* const* img, const int* star
 int bhip_surf_detect_planar_f32(bhip_surf* s, const float* const* bands, int numBands, int startIndex, int stride, int width, int height);
 /* getNumberOfFeatures() of image `image` of the last detect */
 int bhip_surf_count(bhip_surf* s, int image, int* n);
+/* the same for every image of the last batch in one call: counts[i] for i < batch (capacity >= batch) */
+int bhip_surf_counts(bhip_surf* s, int* counts, int capacity);
 /* getLocation(i)/scale -> xy_scale[3n] ; getOrientation(i) -> angle[n] ; BrightFeature.white -> white[n] ;
  * getDescription(i).value -> desc[64n].  getRadius(i) = scale*2 (BoofDefaults.SURF_SCALE_TO_RADIUS).  Any pointer may be NULL. */
 int bhip_surf_fetch(bhip_surf* s, int image, double* xy_scale, double* angle, uint8_t* white, double* desc);

@@ -1268,6 +1268,15 @@ def test_batch_level_fetch_and_resident_association(api, orc):
                 db = desc[int(starts[b]):int(starts[b + 1])]
                 ep, ef = orc.associate_l2(desc[sa], db, maxErr, backwards)
                 assert np.array_equal(pairs[sa], ep) and np.array_equal(fit[sa], ef), (a, b, backwards, maxErr)
+    # images that are the source of no problem read "no match" (-1, 0.0), whatever an earlier call left in the library's scratch
+    pairs, fit = dd.associateImages([1, 3], [2, 4])
+    for a in (0, 2, 4):
+        sa = slice(int(starts[a]), int(starts[a + 1]))
+        assert np.all(pairs[sa] == -1) and np.all(fit[sa] == 0.0), a
+    for a, b in ((1, 2), (3, 4)):
+        sa = slice(int(starts[a]), int(starts[a + 1]))
+        ep, ef = orc.associate_l2(desc[sa], desc[int(starts[b]):int(starts[b + 1])], api.Double_MAX_VALUE, True)
+        assert np.array_equal(pairs[sa], ep) and np.array_equal(fit[sa], ef)
     with pytest.raises(api.IllegalArgumentException):
         dd.associateImages([0, 0], [1, 2])       # an image may be the source of one problem per call
     with pytest.raises(api.IllegalArgumentException):
