@@ -232,32 +232,18 @@ class HostBoundary:
         self.desc = [None] * self.B
         self.matches = 0
 
-    def _detect_range(self, widx, chunks):
-        api = self.api
-        ctx, dd, _ = self.workers[widx]
-        for (a, b) in chunks:
-            imgs = [api.GrayF32(self.w, self.h, self.frames[i].reshape(-1)) for i in range(a, b)]
-            dd.detectBatch(imgs)
-            for j in range(b - a):
-                self.desc[a + j] = dd._results(j)[3]    # bhip_surf_fetch: xy/scale, angle, sign, descriptors to host
-
-    def _assoc_range(self, widx, idx):
-        _, _, assoc = self.workers[widx]
-        m = 0
-        for i in idx:
-            assoc.setSource(self.desc[i]); assoc.setDestination(self.desc[(i + 1) % self.B]); assoc.associate()
-            m += int((assoc.getPairs() >= 0).sum())
-        self._m[widx] = m
-
     _out = None
 
-    def step_batched(self):
+    def step_batched(self, frames_u8=None):
         """The same work through the library's batch-level calls: one bhip_surf_detect_f32 over the whole batch of pinned host frames, one
         bhip_surf_fetch_all (every location / orientation / sign / descriptor to host), one bhip_assoc_l2_surf over the descriptors still
         resident from that detect (matches to host).  What a provider's detectBatch / associate pair costs when it avoids per-frame calls."""
         api = self.api
         ctx, dd, _ = self.workers[0]
-        imgs = [api.GrayF32(self.w, self.h, self.frames[i].reshape(-1)) for i in range(self.B)]
+        if frames_u8 is not None:   # GrayU8 frames: a quarter of the ingest bytes (GrayS32 integral images on the device)
+            imgs = [api.GrayU8(self.w, self.h, frames_u8[i].reshape(-1)) for i in range(self.B)]
+        else:
+            imgs = [api.GrayF32(self.w, self.h, self.frames[i].reshape(-1)) for i in range(self.B)]
         dd.detectBatch(imgs)
         total = dd.totalFeatures()
         if self._out is None or self._out[1].shape[0] < total:
@@ -274,19 +260,52 @@ class HostBoundary:
         return int(starts[-1])
 
     def step(self):
+        """The reference's per-call interface as a two-stage pipeline: one host thread detects (sub-batches) and fetches frame by frame, a
+        second one associates every consecutive pair as soon as both descriptor lists have arrived -- detect is GPU-bound, the per-pair
+        association is bound by its two pageable descriptor uploads, so the two stages overlap (round 2 ran two detect threads, then two
+        association threads: slower than ONE thread, scripts/e2e_strict_breakdown.py)."""
         chunks = [(a, min(a + self.sub, self.B)) for a in range(0, self.B, self.sub)]
-        ts = [threading.Thread(target=self._detect_range, args=(w, chunks[w::2])) for w in range(2)]
+        ready = [threading.Event() for _ in range(self.B)]
+        self.desc = [None] * self.B
+        err = []
+
+        def detect_stage():
+            try:
+                api = self.api
+                ctx, dd, _ = self.workers[0]
+                for (a, b) in chunks:
+                    imgs = [api.GrayF32(self.w, self.h, self.frames[i].reshape(-1)) for i in range(a, b)]
+                    dd.detectBatch(imgs)
+                    for j in range(b - a):
+                        self.desc[a + j] = dd._results(j)[3]    # bhip_surf_fetch: xy/scale, angle, sign, descriptors to host
+                        ready[a + j].set()
+            except Exception as e:   # noqa: BLE001 -- reported by the caller
+                err.append(e)
+                for ev in ready:
+                    ev.set()
+
+        def assoc_stage():
+            try:
+                _, _, assoc = self.workers[1]
+                m = 0
+                for i in range(self.B):
+                    j = (i + 1) % self.B
+                    ready[i].wait(); ready[j].wait()
+                    if err:
+                        return
+                    assoc.setSource(self.desc[i]); assoc.setDestination(self.desc[j]); assoc.associate()
+                    m += int((assoc.getPairs() >= 0).sum())
+                self.matches = m
+            except Exception as e:   # noqa: BLE001
+                err.append(e)
+
+        ts = [threading.Thread(target=detect_stage), threading.Thread(target=assoc_stage)]
         for t in ts:
             t.start()
         for t in ts:
             t.join()
-        self._m = [0, 0]
-        ts = [threading.Thread(target=self._assoc_range, args=(w, range(w, self.B, 2))) for w in range(2)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        self.matches = sum(self._m)
+        if err:
+            raise err[0]
         return sum(len(d) for d in self.desc)
 
 
@@ -498,14 +517,31 @@ def run_frames(args, D):
             kp_b = hb.step_batched()
         D.barrier()
         dtb = D.max(time.perf_counter() - t0)
-        batched = {"value": round(D.world * B * reps / dtb, 1), "unit": "frames/s", "ms_per_batch": round(1e3 * dtb / reps, 2),
+        # the same batch-level calls on GrayU8 frames (the frames rounded to bytes, page-locked): 2.07 MB instead of 8.29 MB per frame over PCIe
+        host_u8 = torch.empty((B, H, W), dtype=torch.uint8, pin_memory=True)
+        host_u8.copy_(frames.clamp(0, 255).to(torch.uint8))
+        torch.cuda.synchronize()
+        u8 = host_u8.numpy()
+        hb.step_batched(u8)
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            kp_u8 = hb.step_batched(u8)
+        D.barrier()
+        dtu = D.max(time.perf_counter() - t0)
+        batched_u8 = {"value": round(D.world * B * reps / dtu, 1), "unit": "frames/s", "ms_per_batch": round(1e3 * dtu / reps, 2),
+                      "path": "the same three calls on GrayU8 frames (bhip_surf_detect_u8: GrayS32 integral images, integer taps)",
+                      "h2d_bytes_per_frame": H * W, "d2h_bytes_per_frame": int((kp_u8 * (64 * 8 + 3 * 8 + 8 + 1) + kp_u8 * 12) / B),
+                      "pcie_ceiling_frames_per_s": round(PCIE_GBS * 1e9 / (H * W), 1), "keypoints_per_frame": round(kp_u8 / B, 1)}
+        del host_u8
+        batched = {"value": round(D.world * B * reps / dtb, 1), "unit": "frames/s", "ms_per_batch": round(1e3 * dtb / reps, 2), "gray_u8": batched_u8,
                    "path": "one bhip_surf_detect_f32 over the %d pinned host frames + one bhip_surf_fetch_all into page-locked result arrays + one bhip_assoc_l2_surf (descriptors stay "
                            "resident for the association, matches come back to the host)" % B,
                    "h2d_bytes_per_frame": H * W * 4, "d2h_bytes_per_frame": int((kp_b * (64 * 8 + 3 * 8 + 8 + 1) + kp_b * 12) / B),
                    "pcie_ceiling_frames_per_s": round(PCIE_GBS * 1e9 / (H * W * 4), 1), "matches_per_frame": round(hb.matches / B, 1)}
         e2e = {"value": round(D.world * B * reps / dt, 1), "unit": "frames/s", "ms_per_batch": round(1e3 * dt / reps, 2),
-               "path": "bhip_surf_detect_f32 (pinned host frames, sub-batches of %d, 2 host threads / streams) + bhip_surf_fetch per frame + "
-                       "bhip_assoc_l2_f64 per consecutive pair" % hb.sub,
+               "path": "bhip_surf_detect_f32 (pinned host frames, sub-batches of %d) + bhip_surf_fetch per frame on one host thread, "
+                       "bhip_assoc_l2_f64 per consecutive pair on a second one as the descriptor lists arrive" % hb.sub,
                "h2d_bytes_per_frame": int(h2d / B), "d2h_bytes_per_frame": int(d2h / B),
                "pcie_ceiling_frames_per_s": round(PCIE_GBS * 1e9 / (h2d / B), 1), "pcie_peak_GBs": PCIE_GBS,
                "matches_per_frame": round(matches_strict / B, 1), "batched_calls": batched}
@@ -575,6 +611,14 @@ def run_frames(args, D):
         roofline["kernels_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         roofline["hbm_gbs_by_kernel"] = {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}
         roofline["tflops_by_kernel"] = {k: round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}
+        # the association stage as a whole: the N x M x 64 contraction of SURVEY 8d counted ONCE (the two matrix-core passes each issue it)
+        as_ms = sum(v["ms"] for k, v in prof.items() if k.startswith("k_assoc"))
+        p1 = prof.get("k_assoc_mfma_pass1")
+        if as_ms > 0 and p1 and p1["flops"] > 0:
+            tf = p1["flops"] / (as_ms / 1e3) / 1e12
+            roofline["assoc_stage"] = {"ms_per_step": round(as_ms / steps, 3), "algorithmic_TFLOPs": round(tf, 1),
+                                       "stage_frac_fp16_mfma_peak": round(tf / FP16_MFMA_PEAK_TFLOPS, 4), "stage_frac_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                       "note": "fp16 MFMA candidate filter (two passes) + exact fp64 re-score of the listed pairs; results are exact"}
         # the detect stage as a whole (a1-a4) against its HBM roofline: SURVEY 8d's 66.5 * P bytes per frame
         det_ms = sum(v["ms"] for k, v in prof.items() if k.startswith(("k_integral", "k_detect_fused", "k_hessian", "k_nms", "k_word_prefix", "k_rank_scatter")))
         if det_ms > 0:
