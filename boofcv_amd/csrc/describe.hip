@@ -58,6 +58,7 @@ struct DescParams {
 	int serialOnly;           // BHIP_DESCRIBE_SERIAL=1: always run the reference's serial window sweep (cross-check of the parallel form)
 #ifdef BHIP_EXPERIMENTS
 	int stopAfter;            // BHIP_DESCRIBE_STOP=k: waves return at phase boundary k (instruction counts per phase by difference; results are garbage)
+	int windowStop;           // BHIP_DESCRIBE_WSTOP=k (8..12): the window sweep returns at its internal boundary k (use with BHIP_DESCRIBE_STOP=3)
 #endif
 };
 
@@ -545,8 +546,12 @@ __device__ __forceinline__ bool countingSortScatter(const double (&a)[EPLT], con
 // Returns false when the caller must run the serial sweep (the arrays are then still the sorted samples).
 template <int EPLT>
 __device__ __forceinline__ bool slidingWindowFast(double* dX, double* dY, const double* sA, const float* sF, const unsigned int* bins, unsigned int* marks, int n,
-												   double window, int lane, double& bestX, double& bestY, unsigned long long* st /*diagnostic stamps or nullptr*/) {
+												   double window, int lane, double& bestX, double& bestY, unsigned long long* st /*diagnostic stamps or nullptr*/, int wstop = -1) {
+#ifdef BHIP_EXPERIMENTS
+#define WSTAMP(i) do { if (st && lane == 0) st[i] = __builtin_readcyclecounter(); if (wstop == (i)) { bestX = 1.0; bestY = 0.0; return true; } } while (0)
+#else
 #define WSTAMP(i) do { if (st && lane == 0) st[i] = __builtin_readcyclecounter(); } while (0)
+#endif
 	const int EPL = (n + 63) >> 6;   // <= EPLT
 	const int p0 = lane * EPL;
 	const int cnt = max(0, min(EPL, n - p0));
@@ -955,7 +960,11 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			}
 			ang = so.sA;   // sorted angles; dX, dY hold the sorted samples
 			DSTAMP(2);
-			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, counted ? bins : nullptr, (unsigned int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr);
+			if (T.oriWindow < 3.0 && !P.serialOnly) needSerial = !slidingWindowFast<EPLT>(dX, dY, ang, so.sF, counted ? bins : nullptr, (unsigned int*)(lds + (size_t)24 * n), n, T.oriWindow, lane, bestX, bestY, STAMP ? P.stamps + g * 16 : nullptr
+#ifdef BHIP_EXPERIMENTS
+																				  , P.windowStop
+#endif
+																				  );
 			if (needSerial) {
 				// estimateAngle() exactly as written in the reference, on the arrays already in sorted order (order[k] == k).
 				// Reached for the full-circle regime (all gradients within one window of each other: ramps, flat patches).
@@ -1271,6 +1280,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 	P.sort64 = bhip_env_flag("BHIP_DESCRIBE_SORT64") ? 1 : 0;
 #ifdef BHIP_EXPERIMENTS
 	{ const char* e = getenv("BHIP_DESCRIBE_STOP"); P.stopAfter = e ? atoi(e) : -1; }
+	{ const char* e = getenv("BHIP_DESCRIBE_WSTOP"); P.windowStop = e ? atoi(e) : -1; }
 #endif
 	if (t.oriWidth * t.oriWidth > 64 * ORI_EPL_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "orientation sample grid too large for the GPU path");
 	if (t.widthSubRegion + 2 * (t.stable ? t.overLap : 0) > DESC_ROW_MAX) return bhip_fail(ctx, BHIP_ERR_UNSUPPORTED, "SURF sub-region too wide for the GPU path");

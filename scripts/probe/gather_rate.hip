@@ -72,6 +72,31 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ img, i
 				const F2 a = *(const F2*)(d + s1 + r), b = *(const F2*)(d + s4 + r);
 				acc += (p6 - b.y - p3 + a.y) - (b.x - p9 - a.x + p0) + (p6 - p9 - p5 + p10) - (p4 - p11 - p3 + p0);
 			}
+		} else if (MODE == 9 || MODE == 10) {
+			// quad-per-sample mapping: 16 samples per instruction, the four lanes of a quad take the four taps of one image row of their
+			// sample (row a, rows c1+c2, row b: three instructions per 16 samples, 108 per key point); MODE 10: 4x4 sample groups
+			const int r = max(1, ((int)(3.f * s + 0.5f)) / 2);
+			const int q = lane >> 2, k = lane & 3;
+			const unsigned colOff = k == 0 ? 0u : k == 1 ? (unsigned)r : k == 2 ? (unsigned)r + 1u : 2u * r + 1u;
+			const unsigned offB = (unsigned)(k < 2 ? r : r + 1) * pitch + ((k & 1) ? 2u * r + 1u : 0u);
+			const unsigned offC = (unsigned)(2 * r + 1) * pitch + colOff;
+#pragma unroll 1
+			for (int step = 0; step < 12; step++) {
+				float A[3], B[3], C[3];
+#pragma unroll
+				for (int u = 0; u < 3; u++) {
+					int ix, iy;
+					if (MODE == 9) { ix = 8 * u + (q & 7); iy = 2 * step + (q >> 3); }
+					else { const int g = step * 3 + u; ix = 4 * (g % 6) + (q & 3); iy = 4 * (g / 6) + (q >> 2); }
+					const float rY = (iy - 12) * s, rX = (ix - 12) * s;
+					const int x = (int)(cx + c * rX - sn * rY);
+					const int y = (int)(cy + sn * rX + c * rY);
+					const unsigned s1 = (unsigned)(y - r - 1) * pitch + (x - r - 1);
+					A[u] = d[s1 + colOff]; B[u] = d[s1 + offB]; C[u] = d[s1 + offC];
+				}
+#pragma unroll
+				for (int u = 0; u < 3; u++) acc += (A[u] - B[u]) + C[u];
+			}
 		} else {
 			const int r = max(1, ((int)(3.f * s + 0.5f)) / 2);
 			const int ly = lane >> 3, lx = lane & 7;
@@ -170,9 +195,12 @@ int main(int argc, char** argv) {
 			const double m2 = run<2>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, lb, out);
 			const double m3 = run<3>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, lb, out);
 			const double m4 = run<4>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, lb, out);
+			const double m9 = run<9>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, lb, out);
+			const double m10 = run<10>(img, W, H, imgStride, nImg, s, blocks, kpPerWave, lb, out);
 			auto cyc = [&](double ms) { return ms * 1e-3 * clk * cus / kps; };
 			printf("%6.1f   %7.3f (%6.0f, %5.1f)   %7.3f (%6.0f, %5.1f)   %7.3f (%6.0f, %5.1f)   %7.3f (%6.0f, %5.1f)   %7.3f (%6.0f, %5.1f)\n", s,
 				   m0, cyc(m0), cyc(m0) / 90, m1, cyc(m1), cyc(m1) / 108, m2, cyc(m2), cyc(m2) / 50, m3, cyc(m3), cyc(m3) / 108, m4, cyc(m4), cyc(m4) / 9);
+			printf("         quad-per-sample 8x2: %7.3f (%6.0f, %5.1f)   4x4: %7.3f (%6.0f, %5.1f)\n", m9, cyc(m9), cyc(m9) / 108, m10, cyc(m10), cyc(m10) / 108);
 		}
 	}
 	return 0;
