@@ -29,6 +29,7 @@
 //     weights per wait.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 struct DescParams {
 	ImgView ii;
@@ -1038,10 +1039,13 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	const int overLap = CFG == 1 ? 2 : CFG == 2 ? 0 : (T.stable ? T.overLap : 0);
 	const int gridW = regionSize + 2 * overLap;
 	const int nsamp = gridW * gridW;
-	// the samples are widened to double once, when they are stored (each is read by up to 16 output lanes in the sums below)
-	double* sX = (double*)lds;
-	double* sY = sX + nsamp;
-	double* feat = sY + nsamp;
+	// The samples wait in LDS for the sums below.  The default configurations keep them in the tap type (4 bytes: fp32 gradients, or the exact
+	// integer box differences of a GrayS32 integral image) and widen them when they are read -- the same value either way -- so that the
+	// descriptor phase fits the LDS the orientation phase needs (four workgroups per CU); the generic instantiation stores doubles.
+	typedef typename std::conditional<CFG != 0, TAP, double>::type SampT;
+	SampT* sX = (SampT*)lds;
+	SampT* sY = sX + nsamp;
+	double* feat = (double*)(sY + nsamp);   // 8-byte aligned: nsamp is even for the default grids
 	// Laplacian sign (computeLaplaceSign): kernelDerivXX(9s) + kernelDerivYY(9s) at the rounded location = four clamped box sums of
 	// four corners each.  Lane t < 16 fetches corner (t & 3) of box (t >> 2) now; the sign is assembled at the end of the kernel, so
 	// the scattered loads are hidden behind the descriptor work.
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 					TAP gx, gy;
 					gradFinish<TAP>(tp[u], gx, gy);
 					const int ix = 8 * u + lx;
-					if (iy < gridW && ix < gridW) { sX[iy * gridW + ix] = (double)gx; sY[iy * gridW + ix] = (double)gy; }
+					if (iy < gridW && ix < gridW) { sX[iy * gridW + ix] = (SampT)gx; sY[iy * gridW + ix] = (SampT)gy; }
 				}
 			}
 		} else {
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 			for (int u = 0; u < DESC_BATCH; u++) {
 				TAP gx, gy;
 				gradFinish<TAP>(tp[u], gx, gy);
-				if (at[u] >= 0) { sX[at[u]] = (double)gx; sY[at[u]] = (double)gy; }
+				if (at[u] >= 0) { sX[at[u]] = (SampT)gx; sY[at[u]] = (SampT)gy; }
 			}
 		}
 		}
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 #pragma unroll 3
 		for (int t = q; t < nT; t += 4) {
 			const int i = t / T_w, j = t - i * T_w;
-			const double vx = sX[base + i * gridW + j], vy = sY[base + i * gridW + j];
+			const double vx = (double)sX[base + i * gridW + j], vy = (double)sY[base + i * gridW + j];
 			const double w = stableDesc ? T.weightSub[t] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
 			const double dx = w * vx, dy = w * vy;
 			const double pdx = c * dx + s * dy;
@@ -1191,8 +1195,8 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 #pragma unroll
 			for (int j = 0; j < TWT; j++) {
 				const bool on = j < T_w;
-				vx[j] = on ? sX[index + j] : 0.0;
-				vy[j] = on ? sY[index + j] : 0.0;
+				vx[j] = on ? (double)sX[index + j] : 0.0;
+				vy[j] = on ? (double)sY[index + j] : 0.0;
 				w[j] = !on ? 0.0 : stableDesc ? T.weightSub[i * T_w + j] : T.weightFast[(regionR + rY + i) * regionSize + regionR + rX + j];
 			}
 #pragma unroll
@@ -1247,6 +1251,14 @@ __global__ __launch_bounds__(256) void k_describe(DescParams P) {
 	DSTAMP(6);
 }
 
+// 1 = FactoryDetectDescribe.surfStable defaults, 2 = surfFast defaults (the CFG template argument of k_describe), 0 = anything else
+static int bhip_describe_default_cfg(const SurfTables& t) {
+	const bool defGrid = t.widthLargeGrid == 4 && t.widthSubRegion == 5 && t.dof == 64;
+	if (defGrid && t.stable && t.overLap == 2 && t.oriStable && t.oriWidth == 17) return 1;
+	if (defGrid && !t.stable && !t.oriStable && t.oriWidth == 13) return 2;
+	return 0;
+}
+
 int bhip_describe_lds_bytes(const SurfTables& t, int nBands) {
 	const int n = t.oriWidth * t.oriWidth;
 	// merge-sort path: 28n while sorting, then dX dY sA Esched + the fp32 copy of the sorted angles (32n); counting-sort path: dX dY sA Esched
@@ -1255,7 +1267,9 @@ int bhip_describe_lds_bytes(const SurfTables& t, int nBands) {
 	const int overLap = t.stable ? t.overLap : 0;
 	const int gridW = t.widthLargeGrid * t.widthSubRegion + 2 * overLap;
 	const int ns = gridW * gridW;
-	const int desc = 2 * ns * 8 + t.dof * 8 * (nBands > 0 ? nBands : 1);
+	// sX sY | feat; the default configurations store 4-byte samples (see k_describe)
+	const int sampBytes = bhip_describe_default_cfg(t) ? 4 : 8;
+	const int desc = 2 * ns * sampBytes + t.dof * 8 * (nBands > 0 ? nBands : 1);
 	int b = ori > desc ? ori : desc;
 	return (b + 15) & ~15;
 }
@@ -1299,7 +1313,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 			{
 				const int epl = (t.oriWidth * t.oriWidth + 63) / 64;
 				const int tw = t.widthSubRegion + 2 * (t.stable ? t.overLap : 0);
-				if (epl == 5 && tw == 9 && t.stable && t.overLap == 2 && t.widthLargeGrid == 4 && t.oriStable) hipLaunchKernelGGL((k_describe<true, 5, 9, float, 1>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
+				if (bhip_describe_default_cfg(t) == 1) hipLaunchKernelGGL((k_describe<true, 5, 9, float, 1>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 				else hipLaunchKernelGGL((k_describe<true, 8, 16, float>), dim3((unsigned)blocks), dim3(256), (size_t)P.ldsPerWave * 4, ctx->stream, P);
 			}
 			std::vector<unsigned long long> h((size_t)total * 16);
@@ -1342,9 +1356,7 @@ int bhip_launch_describe_ex(bhip_ctx* ctx, ImgView ii, const KeyPoint* kps, int 
 		{ const char* e = getenv("BHIP_DESCRIBE_LDSPAD"); if (e) ldsBytes += (size_t)atoi(e); }   // occupancy experiments only
 #endif
 		// default configurations get compile-time sizes (CFG 1 / 2); anything else runs the generic instantiations
-		const bool defGrid = t.widthLargeGrid == 4 && t.widthSubRegion == 5 && t.dof == 64;
-		const bool cfgStable = defGrid && t.stable && t.overLap == 2 && t.oriStable && t.oriWidth == 17;
-		const bool cfgFast = defGrid && !t.stable && !t.oriStable && t.oriWidth == 13;
+		const bool cfgStable = bhip_describe_default_cfg(t) == 1, cfgFast = bhip_describe_default_cfg(t) == 2;
 		const bool ints = planar && planar->intTaps;   // GrayS32 integral image(s)
 		const void* fn;
 		if (cfgStable) fn = ints ? (const void*)k_describe<false, 5, 9, int, 1> : (const void*)k_describe<false, 5, 9, float, 1>;

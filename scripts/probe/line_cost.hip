@@ -10,10 +10,10 @@ __device__ __forceinline__ unsigned hashu(unsigned x) { x ^= x >> 16; x *= 0x7fe
 // wsLines: working set in lines per workgroup-region; each CU's waves draw lines from a region of that many lines
 // SPREAD: 0 = the G lanes of a group read consecutive dwords of the line, 1 = all read the same dword
 template <int G, int WIDTH>
-__global__ __launch_bounds__(256) void k_lines(const float* __restrict__ img, unsigned wsLines, int iters, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_lines(const float* __restrict__ img, unsigned wsLines, int iters, float* __restrict__ out, unsigned nRegions) {
 	const int lane = threadIdx.x & 63;
 	const unsigned grp = lane / G, within = lane % G;
-	const unsigned regionBase = (blockIdx.x % 1024u) * wsLines;   // lines
+	const unsigned regionBase = (blockIdx.x % nRegions) * wsLines;   // lines
 	float acc = 0.f;
 	unsigned h = hashu(blockIdx.x * 256u + (threadIdx.x >> 6) * 64u);
 #pragma unroll 1
@@ -37,14 +37,14 @@ __global__ __launch_bounds__(256) void k_lines(const float* __restrict__ img, un
 }
 
 template <int G, int WIDTH>
-double run(const float* img, unsigned wsLines, float* out) {
+double run(const float* img, unsigned wsLines, float* out, unsigned nRegions = 1024) {
 	const int blocks = 256 * 4 * 4, iters = 512;
 	hipEvent_t a, b;
 	CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-	hipLaunchKernelGGL((k_lines<G, WIDTH>), dim3(blocks), dim3(256), 0, 0, img, wsLines, iters, out);
+	hipLaunchKernelGGL((k_lines<G, WIDTH>), dim3(blocks), dim3(256), 0, 0, img, wsLines, iters, out, nRegions);
 	CHECK(hipDeviceSynchronize());
 	CHECK(hipEventRecord(a));
-	hipLaunchKernelGGL((k_lines<G, WIDTH>), dim3(blocks), dim3(256), 0, 0, img, wsLines, iters, out);
+	hipLaunchKernelGGL((k_lines<G, WIDTH>), dim3(blocks), dim3(256), 0, 0, img, wsLines, iters, out, nRegions);
 	CHECK(hipEventRecord(b));
 	CHECK(hipEventSynchronize(b));
 	float ms = 0;
@@ -73,5 +73,14 @@ int main() {
 		printf("  dwordx4  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f\n", run<1, 4>(img, ws, out), run<2, 4>(img, ws, out), run<4, 4>(img, ws, out), run<8, 4>(img, ws, out),
 			   run<16, 4>(img, ws, out), run<32, 4>(img, ws, out), run<64, 4>(img, ws, out));
 	}
+	// L1 misses that hit the XCD's L2: every workgroup draws from the same few regions (2 MB in all, resident in each XCD's 4 MB L2)
+	printf("L2-resident: 16 regions x 1024 lines shared by all workgroups (2 MB)\n");
+	printf("  dword    %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f\n", run<1, 1>(img, 1024, out, 16), run<2, 1>(img, 1024, out, 16), run<4, 1>(img, 1024, out, 16), run<8, 1>(img, 1024, out, 16),
+		   run<16, 1>(img, 1024, out, 16), run<32, 1>(img, 1024, out, 16), run<64, 1>(img, 1024, out, 16));
+	printf("  dwordx4  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f\n", run<1, 4>(img, 1024, out, 16), run<2, 4>(img, 1024, out, 16), run<4, 4>(img, 1024, out, 16), run<8, 4>(img, 1024, out, 16),
+		   run<16, 4>(img, 1024, out, 16), run<32, 4>(img, 1024, out, 16), run<64, 4>(img, 1024, out, 16));
+	printf("L2-resident: 4 regions x 1024 lines (512 KB)\n");
+	printf("  dword    %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f  %9.1f\n", run<1, 1>(img, 1024, out, 4), run<2, 1>(img, 1024, out, 4), run<4, 1>(img, 1024, out, 4), run<8, 1>(img, 1024, out, 4),
+		   run<16, 1>(img, 1024, out, 4), run<32, 1>(img, 1024, out, 4), run<64, 1>(img, 1024, out, 4));
 	return 0;
 }
