@@ -135,24 +135,29 @@ __global__ __launch_bounds__(256) void k_integral_cols(ImgViewW io) {
 // ---------------------------------------------------------------------------------------------------------------
 #define FT 32   // tile columns
 #define FP 33   // LDS pitch: (row * 33 + k) % 32 == (row + k) % 32
-#define FUSED_TILE_FLOATS (16 * 64 * FP)
 #define FUSED_RING_FLOATS (2 * 16 * FT)
-#define FUSED_MIN_BATCH 128   // an image takes ~0.8 ms through its one workgroup whatever the batch (120 pipeline steps of ~7 us, set by
+#define FUSED_MIN_BATCH 128   // an image takes ~0.8 ms through its one workgroup whatever the batch (pipeline steps of ~7 us, set by
                               // memory latency with one tile of look-ahead); the two streaming passes are faster below ~128 images
                               // (1080p: 0.72 vs 0.84 ms at 96, 0.96 vs 0.85 at 128, 1.81 vs 1.08-1.16 at 256)
 
+// BH = rows per band: 64, 68 or 72 (even; the tiles of the 16 waves have to fit the LDS).  A band taller than 64 rows gives lanes
+// 0 .. BH - 65 a second row (rows 64 .. BH - 1) with a row chain of its own.  The launch picks the height that needs the fewest rounds of 16
+// bands: a 1080-row frame is 16 bands of 68 rows -- one round, every wave busy -- where 64-row bands leave a 17th band to run alone for a
+// whole second round.
+template <int BH>
 __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW out) {
-	extern __shared__ float fusedLds[];   // [16][64 * FP] tiles | [2][16][FT] ring | [W] wrap row (only with more than 16 bands)
+	static_assert(BH >= 64 && BH <= 128 && (BH & 1) == 0, "band height");
+	extern __shared__ float fusedLds[];   // [16][BH * FP] tiles | [2][16][FT] ring | [W] wrap row (only with more than 16 bands)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-	float* tile = fusedLds + wave * 64 * FP;
-	float* ring = fusedLds + FUSED_TILE_FLOATS;
+	float* tile = fusedLds + wave * BH * FP;
+	float* ring = fusedLds + 16 * BH * FP;
 	float* wrapRow = ring + FUSED_RING_FLOATS;
 	const int half = lane >> 5, c = lane & 31;
 	const int W = in.width, H = in.height;
 	const float* __restrict__ src = in.data + (long long)blockIdx.x * in.imageStride;
 	float* __restrict__ dst = out.data + (long long)blockIdx.x * out.imageStride;
 	const int nTiles = (W + FT - 1) / FT;
-	const int nBands = (H + 63) / 64;
+	const int nBands = (H + BH - 1) / BH;
 	const int rounds = (nBands + 15) / 16;
 	const int S = max(nTiles, 16);
 	const int T = (rounds - 1) * S + 16 + nTiles;   // steps; identical for every wave
@@ -167,21 +172,21 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 		const int bb = wave + 16 * r;
 		if (r < rounds && bb < nBands && j < nTiles) b = bb;
 	};
-	// Full tiles (64 rows, 32 columns inside the image: all but the last band / last tile) take a path without per-element guards and
+	// Full tiles (BH rows, 32 columns inside the image: all but the last band / last tile) take a path without per-element guards and
 	// with scalar row bases + one 32-bit lane offset, so a load or store costs one instruction; the guarded form handles the edges.
 	const unsigned laneOffIn = (unsigned)(half * in.stride + c), laneOffOut = (unsigned)(half * out.stride + c);
 	auto loadTile = [&](int b, int j, float* v) {
-		const int y0 = 64 * b;
-		const int nrows = min(64, H - y0);
+		const int y0 = BH * b;
+		const int nrows = min(BH, H - y0);
 		if (FT * j + FT <= W) {
 			const float* __restrict__ base = src + (long long)y0 * in.stride + FT * j;   // wave-uniform
-			if (nrows == 64) {
+			if (nrows == BH) {
 #pragma unroll
-				for (int i = 0; i < 32; i++) v[i] = (base + (long long)(2 * i) * in.stride)[laneOffIn];
+				for (int i = 0; i < BH / 2; i++) v[i] = (base + (long long)(2 * i) * in.stride)[laneOffIn];
 			} else {
 				// last band: the row tests are wave-uniform (scalar branches), only an odd last row needs a lane predicate
 #pragma unroll
-				for (int i = 0; i < 32; i++) {
+				for (int i = 0; i < BH / 2; i++) {
 					const float* rp = base + (long long)(2 * i) * in.stride;
 					if (2 * i + 1 < nrows) v[i] = rp[laneOffIn];
 					else if (2 * i < nrows) v[i] = half == 0 ? rp[laneOffIn] : 0.0f;
@@ -192,13 +197,13 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 		}
 		const int col = FT * j + c;
 #pragma unroll
-		for (int i = 0; i < 32; i++) {
+		for (int i = 0; i < BH / 2; i++) {
 			const int row = 2 * i + half;
 			v[i] = (row < nrows && col < W) ? src[(long long)(y0 + row) * in.stride + col] : 0.0f;
 		}
 	};
-	float v[32];
-	float carry = 0.0f;
+	float v[BH / 2];
+	float carry = 0.0f, carry2 = 0.0f;   // row chains of rows `lane` and `lane + 64`
 	{
 		int b, j;
 		slot(0, b, j);
@@ -208,15 +213,15 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 		int b, j;
 		slot(t, b, j);
 		if (b >= 0) {
-			const int y0 = 64 * b;
-			const int nrows = min(64, H - y0);
-			if (j == 0) carry = 0.0f;
+			const int y0 = BH * b;
+			const int nrows = min(BH, H - y0);
+			if (j == 0) { carry = 0.0f; carry2 = 0.0f; }
 			const int colC = FT * j + c;
 			// the integral-image row above this band, for the tile's columns
 			float top = 0.0f;
 			if (b > 0 && half == 0) top = wave > 0 ? ring[((t - 1) & 1) * 16 * FT + (wave - 1) * FT + c] : wrapRow[min(colC, W - 1)];
 #pragma unroll
-			for (int i = 0; i < 32; i++) tile[(2 * i + half) * FP + c] = v[i];
+			for (int i = 0; i < BH / 2; i++) tile[(2 * i + half) * FP + c] = v[i];
 			// next step's tile: its loads complete under this step's scans
 			{
 				int nb, nj;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 			}
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			// row chain: lane = row
+			// row chain: lane = row (and row lane + 64 of a taller band)
 			if (lane < nrows) {
 				float* mine = tile + lane * FP;
 #pragma unroll
@@ -239,6 +244,19 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 					for (int k = 0; k < 16; k++) mine[k0 + k] = q[k];
 				}
 			}
+			if (BH > 64 && lane + 64 < nrows) {
+				float* mine = tile + (lane + 64) * FP;
+#pragma unroll
+				for (int k0 = 0; k0 < FT; k0 += 16) {
+					float q[16];
+#pragma unroll
+					for (int k = 0; k < 16; k++) q[k] = mine[k0 + k];
+#pragma unroll
+					for (int k = 0; k < 16; k++) { carry2 += q[k]; q[k] = carry2; }
+#pragma unroll
+					for (int k = 0; k < 16; k++) mine[k0 + k] = q[k];
+				}
+			}
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			// column chain: lane = column (first half wave); ii[y] = ii[y-1] + s[y], and ii[0] = s[0] on the image's first row
@@ -248,17 +266,17 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 				if (b == 0) { acc = tile[c]; r0 = 1; }
 				// 16 rows at a time: the LDS reads of a batch are issued together, then the dependent adds, then the writes
 #pragma unroll
-				for (int rb = 0; rb < 64; rb += 16) {
+				for (int rb = 0; rb < BH; rb += 16) {
 					if (rb < nrows) {
 						float q[16];
 #pragma unroll
-						for (int k = 0; k < 16; k++) q[k] = tile[(rb + k) * FP + c];   // rows past nrows: guarded below
+						for (int k = 0; k < 16; k++) q[k] = rb + k < BH ? tile[(rb + k) * FP + c] : 0.0f;   // rows past nrows: guarded below
 #pragma unroll
 						for (int k = 0; k < 16; k++)
-							if (rb + k >= r0 && rb + k < nrows) { acc = acc + q[k]; q[k] = acc; }
+							if (rb + k < BH && rb + k >= r0 && rb + k < nrows) { acc = acc + q[k]; q[k] = acc; }
 #pragma unroll
 						for (int k = 0; k < 16; k++)
-							if (rb + k >= r0 && rb + k < nrows) tile[(rb + k) * FP + c] = q[k];
+							if (rb + k < BH && rb + k >= r0 && rb + k < nrows) tile[(rb + k) * FP + c] = q[k];
 					}
 				}
 				// the band's last row for the band below: next wave's ring slot, or the wrap row when that band belongs to wave 0
@@ -271,12 +289,12 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 			if (FT * j + FT <= W) {
 				float* __restrict__ base = dst + (long long)y0 * out.stride + FT * j;   // wave-uniform
-				if (nrows == 64) {
+				if (nrows == BH) {
 #pragma unroll
-					for (int i = 0; i < 32; i++) (base + (long long)(2 * i) * out.stride)[laneOffOut] = tile[(2 * i + half) * FP + c];
+					for (int i = 0; i < BH / 2; i++) (base + (long long)(2 * i) * out.stride)[laneOffOut] = tile[(2 * i + half) * FP + c];
 				} else {
 #pragma unroll
-					for (int i = 0; i < 32; i++) {
+					for (int i = 0; i < BH / 2; i++) {
 						float* rp = base + (long long)(2 * i) * out.stride;
 						if (2 * i + 1 < nrows) rp[laneOffOut] = tile[(2 * i + half) * FP + c];
 						else if (2 * i < nrows && half == 0) rp[laneOffOut] = tile[(2 * i) * FP + c];
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 				}
 			} else {
 #pragma unroll
-				for (int i = 0; i < 32; i++) {
+				for (int i = 0; i < BH / 2; i++) {
 					const int row = 2 * i + half;
 					if (row < nrows && colC < W) dst[(long long)(y0 + row) * out.stride + colC] = tile[row * FP + c];
 				}
@@ -299,19 +317,36 @@ __global__ __launch_bounds__(1024) void k_integral_fused(ImgView in, ImgViewW ou
 	}
 }
 
+// band height of the single-pass kernel for an H-row image: fewest rounds of 16 bands, then the shorter band
+static int fusedBandHeight(int H) {
+	int best = 64, bestRounds = 1 << 30;
+	for (int bh = 64; bh <= 72; bh += 4) {
+		const int rounds = ((H + bh - 1) / bh + 15) / 16;
+		if (rounds < bestRounds) { bestRounds = rounds; best = bh; }
+	}
+	return best;
+}
+
 int bhip_launch_integral(bhip_ctx* ctx, ImgView in, ImgViewW out, int batch) {
 	if (in.width <= 0 || in.height <= 0 || batch <= 0) return BHIP_OK;
 	const bool twoPass = bhip_env_flag("BHIP_INTEGRAL_TWO_PASS");   // parity cross-check of the two integral plans
 	// one workgroup per image only fills the chip with a large batch; small batches keep the two streaming passes
-	const size_t lds = ((size_t)FUSED_TILE_FLOATS + FUSED_RING_FLOATS + (in.height > 1024 ? in.width : 0)) * sizeof(float);
+	int bh = fusedBandHeight(in.height);
+	{ const char* e = getenv("BHIP_INTEGRAL_BAND"); if (e && (atoi(e) == 64 || atoi(e) == 68 || atoi(e) == 72)) bh = atoi(e); }   // parity cross-check of the band heights
+	const bool wrap = (in.height + bh - 1) / bh > 16;
+	const size_t lds = ((size_t)16 * bh * FP + FUSED_RING_FLOATS + (wrap ? in.width : 0)) * sizeof(float);
 	if (!twoPass && batch >= FUSED_MIN_BATCH && in.data != out.data && lds <= 160 * 1024) {
 		// the attribute is per device and this library serves one ctx per (thread, device): remember it in the ctx, not in a static
 		if (lds > ctx->integralLdsAttr) {
-			BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_integral_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_integral_fused<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_integral_fused<68>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_integral_fused<72>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 			ctx->integralLdsAttr = lds;
 		}
 		ProfScope ps(ctx, "k_integral_fused", 8.0 * in.width * in.height * batch);   // 4P read + 4P write
-		hipLaunchKernelGGL(k_integral_fused, dim3(batch), dim3(1024), lds, ctx->stream, in, out);
+		if (bh == 64) hipLaunchKernelGGL(k_integral_fused<64>, dim3(batch), dim3(1024), lds, ctx->stream, in, out);
+		else if (bh == 68) hipLaunchKernelGGL(k_integral_fused<68>, dim3(batch), dim3(1024), lds, ctx->stream, in, out);
+		else hipLaunchKernelGGL(k_integral_fused<72>, dim3(batch), dim3(1024), lds, ctx->stream, in, out);
 		BHIP_HIP(ctx, hipGetLastError());
 		return BHIP_OK;
 	}

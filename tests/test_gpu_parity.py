@@ -338,6 +338,33 @@ def test_integral_single_pass_batched(api, orc, w, h, batch):
         assert np.array_equal(bits(dd.fetchIntegral(pos, w, h)), bits(want[idx[pos]])), pos
 
 
+@pytest.mark.parametrize("w,h", [(333, 217), (200, 1100), (517, 1200), (96, 1080)])
+def test_integral_single_pass_band_heights(api, orc, w, h):
+    """The single-pass integral kernel runs bands of 64, 68 or 72 rows (the launch picks the height with the fewest rounds of 16 bands: 68 for
+    1080 rows); lanes of a taller band carry a second row chain.  Device batches of 130 frames (host batches are chunked and take the
+    streaming passes): every band height must give the oracle's integral image bit for bit -- ragged last band and tile, more than 16 bands
+    (second round + wrap row), one round of tall bands."""
+    torch = pytest.importorskip("torch")
+    import os
+    rng = np.random.default_rng(w * 5 + h)
+    B = 130
+    base = [(rng.uniform(0, 1e4, (h, w))).astype(np.float32) for _ in range(3)]
+    idx = [int(k) for k in rng.integers(0, 3, B)]
+    frames = torch.from_numpy(np.stack([base[k] for k in idx])).cuda()
+    want = [orc.integral(orc.Gray.from_array(f)).array() for f in base]
+    for band in (None, "64", "68", "72"):
+        if band:
+            os.environ["BHIP_INTEGRAL_BAND"] = band
+        try:
+            ctx = api.Context(0, stream=torch.cuda.current_stream(0).cuda_stream)
+            dd = api.FactoryDetectDescribe.surfFast(api.ConfigFastHessian(detectThreshold=1e12), None, None, api.GrayF32, ctx=ctx)   # no key points: integral only
+            dd.detectDevice(frames.data_ptr(), h * w, w, w, h, B)
+            for pos in (0, 1, B // 2, B - 1):
+                assert np.array_equal(bits(dd.fetchIntegral(pos, w, h)), bits(want[idx[pos]])), (band, pos)
+        finally:
+            os.environ.pop("BHIP_INTEGRAL_BAND", None)
+
+
 # ------------------------------------------------------------------------------------------------------------------ association
 def _col(*v):
     return np.array(v, np.float64).reshape(-1, 1)
