@@ -37,6 +37,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CU_COUNT = 256                # MI355X: 8 XCDs x 32 CUs
+ENGINE_CLOCK_HZ = 2.4e9       # peak engine clock (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16: what k_assoc_mfma_* issue)
 INT8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md: I8 MFMA = 2x the BF16 rate (~2.5 PF dense)
@@ -606,8 +608,16 @@ def run_frames(args, D):
             roofline["hbm_frac_from_traffic"] = round(tb / per_launch_s / 1e9 / HBM_PEAK_GBS, 4)
         if tag == "k_describe":
             # a gather stage.  `achieved` follows the contract (algorithmic tap bytes / time) but nearly all of those bytes are
-            # served by L1/L2: what limits the kernel is instruction issue (profiles/*_pmc_insts.txt), not HBM.
-            roofline["limiter"] = "valu-issue (cache-served gathers; see hbm_frac_from_traffic for the bytes that reach HBM)"
+            # served by L1/L2.  What bounds the kernel is the load path's request rate: a wave-wide gather costs one cycle per lane request
+            # (scripts/probe/line_cost.hip), the kernel issues 8146 lane requests per key point (TCP_TOTAL_CACHE_ACCESSES, profiles/r03_pmc_ta.txt:
+            # 12 taps = 10 requests for each of the 289 + 576 samples) -- DESIGN.md section 4, "the load path's cost rule".
+            kps_per_launch = r["bytes"] / r["launches"] / 42041.0   # the per-key-point byte figure the launch was priced with (stable defaults)
+            req = 8146.0 * kps_per_launch
+            rate = req / (per_launch_s * CU_COUNT * ENGINE_CLOCK_HZ)
+            roofline["limiter"] = "load-path request rate (one cycle per lane request and CU; cache-served gathers -- see hbm_frac_from_traffic for the bytes that reach HBM)"
+            roofline["load_path"] = {"lane_requests_per_key_point": 8146, "key_points_per_launch": round(kps_per_launch), "requests_per_cycle_per_cu": round(rate, 3),
+                                     "peak_requests_per_cycle_per_cu": 1.0, "frac": round(rate, 3),
+                                     "note": "request count from rocprofv3 PMC (profiles/r03_pmc_ta.txt), rate rule from scripts/probe/line_cost.hip (profiles/r03_quad_gather_experiment.txt)"}
         roofline["kernels_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         roofline["hbm_gbs_by_kernel"] = {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}
         roofline["tflops_by_kernel"] = {k: round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}
