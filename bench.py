@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CU_COUNT = 256                # MI355X: 8 XCDs x 32 CUs
+PROFILE_EVERY = 4             # per-kernel HIP events on every 4th step of the timed region (see run_frames)
 ENGINE_CLOCK_HZ = 2.4e9       # peak engine clock (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16: what k_assoc_mfma_* issue)
@@ -468,8 +469,16 @@ def run_frames(args, D):
     hp = HotPath(D.local_rank, B, H, W)
 
     kp = [0]
+    # Per-kernel HIP events (the live roofline numbers) bracket every launch of every PROFILE_EVERY-th step of the timed region: an event
+    # pair costs ~10 us of dependency latency per kernel, ~0.4 ms over the ~40 kernels of a step, so bracketing every step would take 2 %
+    # off the throughput it measures.  The sampled steps are ordinary steps of the timed region.
+    sampling = {"on": False, "n": 0, "sampled": 0}
 
     def step():
+        on = sampling["on"] and sampling["n"] % PROFILE_EVERY == 0
+        hp.ctx.profile(on)
+        sampling["n"] += 1
+        sampling["sampled"] += 1 if on else 0
         kp[0] = hp.step(frames)
         trace("step done: %d key points" % kp[0])
         return kp[0]
@@ -478,18 +487,18 @@ def run_frames(args, D):
         step()
     warm = args.warmup
     args.warmup = 0
-    hp.ctx.profile(True)
-    hp.ctx.profileReset()
-    if args.steps is None:   # calibration step runs with profiling on too; reset after it
+    if args.steps is None:
         D.barrier()
         t0 = time.perf_counter(); step(); torch.cuda.synchronize()
         one = D.max(time.perf_counter() - t0)
         args.steps = int(D.max(float(max(3, int(MIN_TIMED_SECONDS / max(one, 1e-6)) + 1))))
-        hp.ctx.profileReset()
+    sampling.update(on=True, n=0, sampled=0)
+    hp.ctx.profileReset()
     steps, elapsed, _ = timed_steps(D, args, step)
     args.warmup = warm
     prof = hp.ctx.profileReport()
     hp.ctx.profile(False)
+    psteps = max(sampling["sampled"], 1)   # steps whose kernels were bracketed
     kp_all = D.sum(float(kp[0]))
 
     # host-boundary leg (every rank runs it at the same time: the ranks share the host's PCIe complex and cores)
@@ -618,7 +627,8 @@ def run_frames(args, D):
             roofline["load_path"] = {"lane_requests_per_key_point": 8146, "key_points_per_launch": round(kps_per_launch), "requests_per_cycle_per_cu": round(rate, 3),
                                      "peak_requests_per_cycle_per_cu": 1.0, "frac": round(rate, 3),
                                      "note": "request count from rocprofv3 PMC (profiles/r03_pmc_ta.txt), rate rule from scripts/probe/line_cost.hip (profiles/r03_quad_gather_experiment.txt)"}
-        roofline["kernels_ms_per_step"] = {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        roofline["kernels_ms_per_step"] = {k: round(v["ms"] / psteps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        roofline["steps_with_kernel_events"] = "%d of %d (every %d. step of the timed region)" % (psteps, steps, PROFILE_EVERY)
         roofline["hbm_gbs_by_kernel"] = {k: round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1) for k, v in prof.items() if v["bytes"] > 0 and v["ms"] > 0}
         roofline["tflops_by_kernel"] = {k: round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2) for k, v in prof.items() if v["flops"] > 0 and v["ms"] > 0}
         # the association stage as a whole: the N x M x 64 contraction of SURVEY 8d counted ONCE (the two matrix-core passes each issue it)
@@ -626,14 +636,14 @@ def run_frames(args, D):
         p1 = prof.get("k_assoc_mfma_pass1")
         if as_ms > 0 and p1 and p1["flops"] > 0:
             tf = p1["flops"] / (as_ms / 1e3) / 1e12
-            roofline["assoc_stage"] = {"ms_per_step": round(as_ms / steps, 3), "algorithmic_TFLOPs": round(tf, 1),
+            roofline["assoc_stage"] = {"ms_per_step": round(as_ms / psteps, 3), "algorithmic_TFLOPs": round(tf, 1),
                                        "stage_frac_fp16_mfma_peak": round(tf / FP16_MFMA_PEAK_TFLOPS, 4), "stage_frac_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
                                        "note": "fp16 MFMA candidate filter (two passes) + exact fp64 re-score of the listed pairs; results are exact"}
         # the detect stage as a whole (a1-a4) against its HBM roofline: SURVEY 8d's 66.5 * P bytes per frame
         det_ms = sum(v["ms"] for k, v in prof.items() if k.startswith(("k_integral", "k_detect_fused", "k_hessian", "k_nms", "k_word_prefix", "k_rank_scatter")))
         if det_ms > 0:
-            det_gbs = 66.5 * W * H * B * steps / (det_ms / 1e3) / 1e9
-            roofline["detect_stage"] = {"ms_per_step": round(det_ms / steps, 3), "algorithmic_GBs": round(det_gbs, 1), "frac": round(det_gbs / HBM_PEAK_GBS, 4)}
+            det_gbs = 66.5 * W * H * B * psteps / (det_ms / 1e3) / 1e9
+            roofline["detect_stage"] = {"ms_per_step": round(det_ms / psteps, 3), "algorithmic_GBs": round(det_gbs, 1), "frac": round(det_gbs / HBM_PEAK_GBS, 4)}
     cpu = None
     if D.world == 1 and args.cpu_frames > 0:
         threads = min(os.cpu_count() or 1, 16)

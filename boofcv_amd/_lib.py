@@ -47,6 +47,8 @@ SIGNATURES = {
     "bhip_ctx_destroy": (_i, [_vp]),
     "bhip_ctx_synchronize": (_i, [_vp]),
     "bhip_last_error": (C.c_char_p, [_vp]),
+    "bhip_host_alloc": (_i, [_vp, C.c_longlong, P(_vp)]),
+    "bhip_host_free": (_i, [_vp]),
     "bhip_version": (C.c_char_p, []),
     "bhip_profile_enable": (_i, [_vp, _i]),
     "bhip_profile_reset": (_i, [_vp]),

@@ -125,6 +125,73 @@ class Context:
 atexit.register(Context._close_all)   # runs before module teardown and before the HIP runtime's own exit handlers
 
 
+class _PinnedPool:
+    """Page-locked host blocks (bhip_host_alloc) for the arrays this wrapper hands out or fills on every call -- fetched key points and
+    descriptors, match lists -- so that their copies are DMA transfers instead of staged pageable copies (what a JNI provider gets from direct
+    ByteBuffers over the same allocator).  Blocks are recycled by size class when the numpy arrays built on them are garbage collected."""
+    _free = {}      # size class -> [address]
+    _closed = False
+    MIN = 4096
+
+    @classmethod
+    def _size_class(cls, nbytes):
+        c = cls.MIN   # 4K, 6K, 8K, 12K, 16K, 24K, ...: powers of two and the sizes half way between them
+        while c < nbytes:
+            c = c * 3 // 2 if c & (c - 1) == 0 else c * 4 // 3
+        return c
+
+    @classmethod
+    def block(cls, ctx, nbytes):
+        """-> (ctypes uint8 array over a pinned block of at least nbytes, or None when pinned memory is not to be had)"""
+        if cls._closed or not ctx._h:
+            return None
+        size = cls._size_class(max(int(nbytes), 1))
+        lst = cls._free.get(size)
+        if lst:
+            addr = lst.pop()
+        else:
+            p = C.c_void_p()
+            if _lib.load().bhip_host_alloc(ctx._h, size, C.byref(p)) != _lib.BHIP_OK or not p.value:
+                return None
+            addr = p.value
+        buf = (C.c_uint8 * size).from_address(addr)
+        weakref.finalize(buf, cls._release, addr, size)
+        return buf
+
+    @classmethod
+    def _release(cls, addr, size, _finalizing=sys.is_finalizing):
+        if cls._closed or _finalizing():
+            return   # the exit hook has run (or the interpreter is going down): the runtime reclaims the block
+        cls._free.setdefault(size, []).append(addr)
+
+    @classmethod
+    def arrays(cls, ctx, specs):
+        """specs = [(shape, dtype), ...] -> numpy arrays carved out of ONE pinned block (64-byte aligned each); pageable arrays when no pinned
+        memory is available.  Contents are uninitialised."""
+        sizes = [int(np.prod(shape)) * np.dtype(dt).itemsize for shape, dt in specs]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) & ~63
+        buf = cls.block(ctx, total) if total else None
+        if buf is None:
+            return [np.empty(shape, dtype=dt) for shape, dt in specs]
+        raw = np.frombuffer(buf, dtype=np.uint8)   # keeps `buf` (and with it the block) alive through .base
+        return [raw[o:o + n].view(dt).reshape(shape) for o, n, (shape, dt) in zip(offs, sizes, specs)]
+
+    @classmethod
+    def _close(cls):
+        cls._closed = True
+        L = _lib.load()
+        for lst in cls._free.values():
+            for addr in lst:
+                L.bhip_host_free(C.c_void_p(addr))
+        cls._free.clear()
+
+
+atexit.register(_PinnedPool._close)   # registered after Context._close_all, so it runs before it (contexts are still alive)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # data types
 # ------------------------------------------------------------------------------------------------------------------
@@ -508,7 +575,8 @@ class DetectDescribePoint:
             n = C.c_int(0)
             _check(self.ctx, L.bhip_surf_count(self._h, image, C.byref(n)))
             n = n.value
-            xys = np.zeros((n, 3)); ang = np.zeros(n); white = np.zeros(n, dtype=np.uint8); desc = np.zeros((n, self._dof))
+            # page-locked result arrays (the copies are DMA transfers; a descriptor list handed on to associate() uploads the same way)
+            xys, ang, white, desc = _PinnedPool.arrays(self.ctx, [((n, 3), np.float64), ((n,), np.float64), ((n,), np.uint8), ((n, self._dof), np.float64)])
             if n:
                 _check(self.ctx, L.bhip_surf_fetch(self._h, image, xys.ctypes.data_as(_lib._dp), ang.ctypes.data_as(_lib._dp),
                                                    white.ctypes.data_as(_lib._u8p), desc.ctypes.data_as(_lib._dp)))
@@ -957,10 +1025,11 @@ class AssociateDescription:
         self.backwardsValidation = bool(backwardsValidation)
         self.listSrc = None
         self.listDst = None
-        self.matches = []
-        self.unassocSrc = []
+        self._matches = []
+        self._unassocSrc = []
         self._pairs = np.zeros(0, dtype=np.int32)
         self._fit = np.zeros(0)
+        self._nd = 0
 
     def setSource(self, listSrc):
         self.listSrc = listSrc
@@ -990,8 +1059,9 @@ class AssociateDescription:
         length = src.shape[1] if ns else (dst.shape[1] if nd else 1)
         if ns and nd and src.shape[1] != dst.shape[1]:
             raise IllegalArgumentException("descriptor lengths differ")
-        pairs = np.full(ns, -1, dtype=np.int32)
-        fit = np.full(ns, self.maxFitError, dtype=np.float64)
+        pairs, fit = _PinnedPool.arrays(self.ctx, [((ns,), np.int32), ((ns,), np.float64)])
+        pairs[:] = -1
+        fit[:] = self.maxFitError
         L = _lib.load()
         if ns:
             if kind == "l2":
@@ -1003,8 +1073,21 @@ class AssociateDescription:
                                                       self.maxFitError, int(self.backwardsValidation), pairs.ctypes.data_as(_lib._ip),
                                                       fit.ctypes.data_as(_lib._dp)))
         self._pairs, self._fit, self._nd = pairs, fit, nd
-        self.matches = [AssociatedIndex(i, int(pairs[i]), float(fit[i])) for i in range(ns) if pairs[i] >= 0]
-        self.unassocSrc = [i for i in range(ns) if pairs[i] < 0]
+        self._matches = None      # the object lists are built when they are asked for (getMatches / getUnassociatedSource)
+        self._unassocSrc = None
+
+    @property
+    def matches(self):
+        if self._matches is None:
+            idx = np.nonzero(self._pairs >= 0)[0]
+            self._matches = [AssociatedIndex(i, d, f) for i, d, f in zip(idx.tolist(), self._pairs[idx].tolist(), self._fit[idx].tolist())]
+        return self._matches
+
+    @property
+    def unassocSrc(self):
+        if self._unassocSrc is None:
+            self._unassocSrc = np.nonzero(self._pairs < 0)[0].tolist()
+        return self._unassocSrc
 
     def getPairs(self):
         return self._pairs

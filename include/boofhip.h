@@ -93,6 +93,12 @@ int bhip_ctx_create_on_stream(int device, void* hip_stream, bhip_ctx** out);
 int bhip_ctx_destroy(bhip_ctx* ctx);
 int bhip_ctx_synchronize(bhip_ctx* ctx);
 const char* bhip_last_error(bhip_ctx* ctx);
+/* Page-locked ("pinned") host memory for the arrays a caller exchanges with the library -- what a JNI provider wraps in direct
+ * ByteBuffers (NewDirectByteBuffer) for frames, fetched results and descriptor lists: copies to and from it are DMA transfers, copies
+ * from ordinary (pageable) arrays go through the runtime's staging buffer.  Every entry point accepts either kind.  The block is not
+ * tied to the context's lifetime; release it with bhip_host_free (a no-op for NULL and once process exit has begun). */
+int bhip_host_alloc(bhip_ctx* ctx, long long bytes, uint8_t** host_mem);
+int bhip_host_free(void* host_mem);
 const char* bhip_version(void);
 /* optional per-kernel timing with HIP events on the ctx stream (bench.py's live roofline numbers).  report writes one text line per
  * kernel tag, "tag launches total_ms algorithmic_bytes algorithmic_flops", and returns the buffer size it needs. */
@@ -109,7 +115,9 @@ int bhip_surf_destroy(bhip_surf* s);
  * as in the reference (DetectDescribePoint.java:38-40). */
 int bhip_surf_detect_f32(bhip_surf* s, const float* const* img, const int* startIndex, const int* stride, int width, int height, int batch);
 /* same on a device-resident batch: image i starts at dev_images + i*imageStride floats, rows are `stride` floats apart.
- * Asynchronous on the ctx stream apart from one small count read-back. */
+ * Asynchronous on the ctx stream apart from one small count read-back: the call returns when the key points are counted (the frames have
+ * been consumed by then), with the describe kernels still queued; counts are valid at once, every fetch waits for the results, device
+ * views (bhip_surf_dev_view) and the resident associations are ordered behind them on the same stream. */
 int bhip_surf_detect_dev_f32(bhip_surf* s, const float* dev_images, long long imageStride, int stride, int width, int height, int batch);
 /* The same on GrayU8 frames: the integral images are GrayS32 (GIntegralImageOps.getIntegralType) and every stage runs on integer taps --
  * IntegralImageOps.transform(GrayU8, GrayS32), FastHessianFeatureDetector<GrayS32>, SparseIntegralGradient_NoBorder_I32 for the
