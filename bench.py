@@ -507,7 +507,7 @@ def run_frames(args, D):
         host = torch.empty((B, H, W), dtype=torch.float32, pin_memory=True)
         host.copy_(frames)
         torch.cuda.synchronize()
-        hb = HostBoundary(D.local_rank, host.numpy(), sub_batch=min(32, B))
+        hb = HostBoundary(D.local_rank, host.numpy(), sub_batch=min(int(os.environ.get("BHIP_BENCH_SUB_BATCH", "64")), B))
         hb.step()   # warm-up: allocations, first-touch
         D.barrier()
         reps = 2 if B >= 64 else 5
@@ -551,8 +551,9 @@ def run_frames(args, D):
                    "h2d_bytes_per_frame": H * W * 4, "d2h_bytes_per_frame": int((kp_b * (64 * 8 + 3 * 8 + 8 + 1) + kp_b * 12) / B),
                    "pcie_ceiling_frames_per_s": round(PCIE_GBS * 1e9 / (H * W * 4), 1), "matches_per_frame": round(hb.matches / B, 1)}
         e2e = {"value": round(D.world * B * reps / dt, 1), "unit": "frames/s", "ms_per_batch": round(1e3 * dt / reps, 2),
-               "path": "bhip_surf_detect_f32 (pinned host frames, sub-batches of %d) + bhip_surf_fetch per frame on one host thread, "
-                       "bhip_assoc_l2_f64 per consecutive pair on a second one as the descriptor lists arrive" % hb.sub,
+               "path": "bhip_surf_detect_f32 (pinned host frames, sub-batches of %d: chunks of 32 whose upload runs under the previous chunk's kernels) + "
+                       "bhip_surf_fetch per frame into page-locked arrays on one host thread, bhip_assoc_l2_f64 per consecutive pair on a second one as the "
+                       "descriptor lists arrive" % hb.sub,
                "h2d_bytes_per_frame": int(h2d / B), "d2h_bytes_per_frame": int(d2h / B),
                "pcie_ceiling_frames_per_s": round(PCIE_GBS * 1e9 / (h2d / B), 1), "pcie_peak_GBs": PCIE_GBS,
                "matches_per_frame": round(matches_strict / B, 1), "batched_calls": batched}
