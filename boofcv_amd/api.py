@@ -146,10 +146,14 @@ class _PinnedPool:
         if cls._closed or not ctx._h:
             return None
         size = cls._size_class(max(int(nbytes), 1))
+        addr = None
         lst = cls._free.get(size)
         if lst:
-            addr = lst.pop()
-        else:
+            try:
+                addr = lst.pop()      # (list.pop is atomic; another thread may have taken the last block in between)
+            except IndexError:
+                addr = None
+        if addr is None:
             p = C.c_void_p()
             if _lib.load().bhip_host_alloc(ctx._h, size, C.byref(p)) != _lib.BHIP_OK or not p.value:
                 return None

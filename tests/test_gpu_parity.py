@@ -1147,6 +1147,48 @@ def test_describe_internal_paths_agree(api, orc):
             assert np.array_equal(base[1], other[1])
 
 
+def test_page_locked_boundary_arrays(api, orc):
+    """bhip_host_alloc / bhip_host_free and the pool the Python mirror builds on them: the arrays _results() and associate() hand out live in
+    page-locked blocks that are recycled when the arrays die, stay readable after their context is closed, and give the same numbers as
+    ordinary (pageable) arrays."""
+    import ctypes as C
+    import gc
+    from boofcv_amd import _lib
+    L = _lib.load()
+    ctx = api.Context(0)
+    p = C.c_void_p()
+    assert L.bhip_host_alloc(ctx._h, 0, C.byref(p)) == _lib.BHIP_ERR_INVALID and not p.value
+    assert L.bhip_host_alloc(ctx._h, 1 << 20, C.byref(p)) == _lib.BHIP_OK and p.value
+    a = np.frombuffer((C.c_uint8 * (1 << 20)).from_address(p.value), dtype=np.float64)
+    a[:] = 3.0
+    assert a.sum() == 3.0 * a.size
+    del a
+    assert L.bhip_host_free(p) == _lib.BHIP_OK and L.bhip_host_free(None) == _lib.BHIP_OK
+    img = orc.noise_image(320, 240, 77)
+    dd = api.FactoryDetectDescribe.surfStable(None, None, None, api.GrayF32, ctx=ctx)
+    dd.detect(G(api, img))
+    xys, ang, white, desc = dd._results(0)
+    n = len(xys)
+    assert n > 50 and desc.shape == (n, 64)
+    addr = desc.ctypes.data
+    pageable = np.array(desc)             # an ordinary copy
+    assoc = api.FactoryAssociation.greedy(api.ScoreAssociateEuclideanSq_F64(), api.Double_MAX_VALUE, True, ctx=ctx)
+    assoc.setSource(desc); assoc.setDestination(desc[::-1].copy()); assoc.associate()
+    pinned_pairs = np.array(assoc.getPairs())
+    assoc.setSource(pageable); assoc.setDestination(pageable[::-1].copy()); assoc.associate()
+    assert np.array_equal(pinned_pairs, assoc.getPairs()) and np.array_equal(pinned_pairs, np.arange(n)[::-1])
+    assert [m.src for m in assoc.getMatches()] == list(range(n)) and assoc.getUnassociatedSource() == []
+    # the block goes back to the pool when the last array on it dies, and the next fetch of the same size takes it again
+    del xys, ang, white, desc
+    dd._cache.clear()
+    gc.collect()
+    again = dd._results(0)
+    assert again[3].ctypes.data == addr and np.array_equal(again[3], pageable)
+    keep = again[3]
+    ctx.close()                            # the arrays outlive the context
+    assert np.array_equal(keep, pageable)
+
+
 @pytest.mark.parametrize("kind", ["l2", "hamming"])
 def test_sharded_association_single_process_ranks(api, orc, kind):
     """SURVEY 8e on one GPU: R simulated ranks run phase 1 on their row slices, the column records are concatenated exactly as
