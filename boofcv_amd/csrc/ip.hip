@@ -176,6 +176,8 @@ __device__ __forceinline__ float4 loadRow4(const float* __restrict__ row, int gx
 // Horizontal pass.  A block takes CT_ROWS rows x 256 columns; wave w stages and filters rows w, w+4, ...: the row segment plus the
 // kernel's reach (rounded to 16-byte chunks) goes to LDS once, then lane l produces columns l, l+64, l+128, l+192 of the segment, so
 // every LDS read and every global store of a wave touches 64 consecutive floats.
+// (Measured alternative that lost: a wave walking a strip of 16 rows through two LDS row buffers of its own, the next row's loads under the
+// tap loop, no block barrier, a quarter of the workgroups: 1.16 ms against 0.85 ms for 41 taps on 64 x 1080p.)
 #define CT_W 256
 #define CT_ROWS 8
 template <int KW>
@@ -195,13 +197,72 @@ __global__ __launch_bounds__(256) void k_conv_h_tile(ConvParams P, int padL, int
 		float* row = lds + (wave + 4 * q) * ldsRow;
 		for (int c = lane; c < nChunks; c += 64) *reinterpret_cast<float4*>(row + 4 * c) = loadRow4(src, xt0 - padL + 4 * c, P.width);
 	}
+	// the kernel's coefficients behind the rows: one broadcast LDS read per tap serves the lane's four outputs
+	float* kl = lds + CT_ROWS * ldsRow;
+	if ((int)threadIdx.x < P.kw) kl[threadIdx.x] = P.k[threadIdx.x];
 	__syncthreads();
+	const int kw = KW > 0 ? KW : P.kw;
+	// Run-time widths: the reference's interior expression -- total = (0 +) s0*k0; total += s_i*k_i in tap order -- is formed for the four
+	// outputs of a lane together (every tap of every output lies inside the staged row, whose cells outside the image hold 0 and are only
+	// ever combined into values that are not stored); interior outputs are stored, the few border outputs of the frame tiles take convOne.
+	const bool fast = KW == 0 && P.mode != 2 && P.mode != 3;
+	const int offRh = kw - P.koff - 1;
 #pragma unroll
 	for (int q = 0; q < CT_ROWS / 4; q++) {
 		const int y = y0 + wave + 4 * q;
 		if (y >= P.height) break;
 		const float* row = lds + (wave + 4 * q) * ldsRow + padL - P.koff;
 		float* dst = outImg + (long long)y * P.outStride;
+		if (fast) {
+			// (the two taps of a pair are 64 words apart: one ds_read2st64_b32 fills a register pair for the packed multiply-add)
+			typedef float f32x2 __attribute__((ext_vector_type(2)));
+			const float* s0 = row + lane;
+			const float k0 = kl[0];
+			f32x2 a = f32x2{s0[0], s0[64]} * k0, b = f32x2{s0[128], s0[192]} * k0;
+			if (!P.unrolled) { a = f32x2{0.0f, 0.0f} + a; b = f32x2{0.0f, 0.0f} + b; }
+			// Four taps per step, the eight pair reads written out: left to itself the compiler pairs ADJACENT taps of one column (ds_read2_b32)
+			// and then spends two moves per tap on re-pairing them for the packed arithmetic (910 vector instructions per wave instead of ~500).
+			int i = 1;
+			unsigned int ad = (unsigned int)(uintptr_t)(s0 + 1);   // LDS byte address of tap 1 of the lane's first output
+			for (; i + 4 <= kw; i += 4, ad += 16u) {
+				f32x2 p0, p1, p2, p3, q0, q1, q2, q3;
+				const unsigned int a1 = ad + 4u, a2 = ad + 8u, a3 = ad + 12u;
+				const float ka = kl[i], kb = kl[i + 1], kc = kl[i + 2], kd = kl[i + 3];   // issued first: the wait below covers them as well
+				asm volatile("ds_read2st64_b32 %0, %8 offset0:0 offset1:1\n\t"
+							 "ds_read2st64_b32 %4, %8 offset0:2 offset1:3\n\t"
+							 "ds_read2st64_b32 %1, %9 offset0:0 offset1:1\n\t"
+							 "ds_read2st64_b32 %5, %9 offset0:2 offset1:3\n\t"
+							 "ds_read2st64_b32 %2, %10 offset0:0 offset1:1\n\t"
+							 "ds_read2st64_b32 %6, %10 offset0:2 offset1:3\n\t"
+							 "ds_read2st64_b32 %3, %11 offset0:0 offset1:1\n\t"
+							 "ds_read2st64_b32 %7, %11 offset0:2 offset1:3\n\t"
+							 "s_waitcnt lgkmcnt(0)"
+							 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+							 : "v"(ad), "v"(a1), "v"(a2), "v"(a3)
+							 : "memory");
+				a += p0 * ka; b += q0 * ka;
+				a += p1 * kb; b += q1 * kb;
+				a += p2 * kc; b += q2 * kc;
+				a += p3 * kd; b += q3 * kd;
+			}
+			for (; i < kw; i++) {
+				const float k = kl[i];
+				a += f32x2{s0[i], s0[64 + i]} * k;
+				b += f32x2{s0[128 + i], s0[192 + i]} * k;
+			}
+			const float t[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int xl = lane + 64 * j, x = xt0 + xl;
+				if (x >= P.width) continue;
+				if (x >= P.koff && x < P.width - offRh) dst[x] = t[j];
+				else {
+					float r;
+					if (convOne<KW>(P, row + xl, 1, x, P.width, r)) dst[x] = r;
+				}
+			}
+			continue;
+		}
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int xl = lane + 64 * j, x = xt0 + xl;
@@ -215,8 +276,10 @@ __global__ __launch_bounds__(256) void k_conv_h_tile(ConvParams P, int padL, int
 // instruction, 16 bytes per lane), then wave w filters rows w, w+4, ...; lane l owns columns 4l .. 4l+3, so taps are ds_read_b128
 // and results leave as 16-byte stores.
 #define CV_ROWS 32
-template <int KW>
-__global__ __launch_bounds__(256) void k_conv_v_tile(ConvParams P) {
+// NW = waves per block.  The run-time widths (wide kernels) run 16 waves per block: a block's LDS is (CV_ROWS + kw - 1) KB -- 72 KB for 41 taps, two
+// blocks per CU -- so four waves per block left two waves per SIMD to hide the LDS latency of a tap loop (41 taps: 0.81 -> 0.53 ms per 64 x 1080p).
+template <int KW, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_conv_v_tile(ConvParams P) {
 	extern __shared__ float lds[];
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int x = blockIdx.x * CT_W + 4 * lane;
@@ -227,17 +290,38 @@ __global__ __launch_bounds__(256) void k_conv_v_tile(ConvParams P) {
 	const int nStage = min(CV_ROWS, P.height - y0) + kw - 1;
 	const int yTop = y0 - P.koff;
 	if (x < P.width) {
-		for (int i = wave; i < nStage; i += 4) {
+		for (int i = wave; i < nStage; i += NW) {
 			const int yy = yTop + i;
 			if (yy >= 0 && yy < P.height) *reinterpret_cast<float4*>(lds + i * CT_W + 4 * lane) = loadRow4(img + (long long)yy * P.inStride, x, P.width);
 		}
 	}
+	float* kl = lds + (CV_ROWS + kw - 1) * CT_W;   // the kernel's coefficients behind the rows (one broadcast read per tap)
+	if ((int)threadIdx.x < kw) kl[threadIdx.x] = P.k[threadIdx.x];
 	__syncthreads();
 	if (x >= P.width) return;
-	for (int q = wave; q < CV_ROWS; q += 4) {
+	const int offR = kw - P.koff - 1;
+	for (int q = wave; q < CV_ROWS; q += NW) {
 		const int y = y0 + q;
 		if (y >= P.height) break;
 		const float* s = lds + q * CT_W + 4 * lane;
+		if (KW == 0 && P.mode != 2 && P.mode != 3 && y >= P.koff && y < P.height - offR && x + 3 < P.width) {
+			// interior row (wave-uniform): the lane's four columns together, taps as 16-byte LDS reads, packed fp32 -- per column the
+			// reference's expression, total = (0 +) s0*k0; total += s_i*k_i in tap order
+			typedef float f32x2 __attribute__((ext_vector_type(2)));
+			const float4 v0 = *reinterpret_cast<const float4*>(s);
+			const float k0 = kl[0];
+			f32x2 lo = f32x2{v0.x, v0.y} * k0, hi = f32x2{v0.z, v0.w} * k0;
+			if (!P.unrolled) { lo = f32x2{0.0f, 0.0f} + lo; hi = f32x2{0.0f, 0.0f} + hi; }
+#pragma unroll 4
+			for (int i = 1; i < kw; i++) {
+				const float4 v = *reinterpret_cast<const float4*>(s + i * CT_W);
+				const float k = kl[i];
+				lo += f32x2{v.x, v.y} * k;
+				hi += f32x2{v.z, v.w} * k;
+			}
+			*reinterpret_cast<float4*>(outImg + (long long)y * P.outStride + x) = make_float4(lo.x, lo.y, hi.x, hi.y);
+			continue;
+		}
 		float r[4];
 		bool wr = true;
 #pragma unroll
@@ -593,20 +677,15 @@ int bhip_launch_conv(bhip_ctx* ctx, bool vertical, bool normalized, const float*
 		}
 	} else if (vertical) {
 		dim3 grid((width + CT_W - 1) / CT_W, (height + CV_ROWS - 1) / CV_ROWS, batch);
-		const size_t ldsBytes = (size_t)(CV_ROWS + kw - 1) * CT_W * 4;
-#define LAUNCH_V(KWT)                                                                                                   \
-	do {                                                                                                                \
-		if (ldsBytes > 65536) BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_conv_v_tile<KWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes)); \
-		hipLaunchKernelGGL(k_conv_v_tile<KWT>, grid, dim3(256), ldsBytes, ctx->stream, P);                              \
-	} while (0)
-		LAUNCH_V(0);
-#undef LAUNCH_V
+		const size_t ldsBytes = (size_t)(CV_ROWS + kw - 1) * CT_W * 4 + (size_t)kw * 4;   // rows + the kernel
+		if (ldsBytes > 65536) BHIP_HIP(ctx, hipFuncSetAttribute((const void*)k_conv_v_tile<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+		hipLaunchKernelGGL((k_conv_v_tile<0, 16>), grid, dim3(1024), ldsBytes, ctx->stream, P);
 	} else {
 		const int offR = kw - koff - 1;
 		const int padL = (koff + 3) & ~3, padR = (offR + 3) & ~3;
 		const int ldsRow = CT_W + padL + padR;
 		dim3 grid((width + CT_W - 1) / CT_W, (height + CT_ROWS - 1) / CT_ROWS, batch);
-		const size_t ldsBytes = (size_t)CT_ROWS * ldsRow * 4;
+		const size_t ldsBytes = (size_t)CT_ROWS * ldsRow * 4 + (size_t)kw * 4;   // rows + the kernel
 #define LAUNCH_H(KWT) hipLaunchKernelGGL(k_conv_h_tile<KWT>, grid, dim3(256), ldsBytes, ctx->stream, P, padL, ldsRow)
 		LAUNCH_H(0);
 #undef LAUNCH_H
