@@ -119,8 +119,11 @@ __global__ __launch_bounds__(256) void k_conv(ConvParams P) {
 //   interior            total = s0*k0 (unrolled widths) or 0 + s0*k0 (standard), then total += s_i*k_i in tap order
 //   border, normalised  weight += k; total += s*k over the taps inside the image, total / weight   (ConvolveNormalized_JustBorder_SB)
 // KW > 0: compile-time width (the reference's unrolled widths 3..11), KW == 0: run-time width.  Returns false when the pixel is not written.
+// kc: where the coefficients are read from -- the kernel arguments by default; the tiled kernels pass their LDS copy (a run-time index into
+// the argument block is a memory access per tap)
 template <int KW>
-__device__ __forceinline__ bool convOne(const ConvParams& P, const float* s, int step, int pos, int extent, float& result) {
+__device__ __forceinline__ bool convOne(const ConvParams& P, const float* s, int step, int pos, int extent, float& result, const float* kc = nullptr) {
+	if (!kc) kc = P.k;
 	const int kw = KW > 0 ? KW : P.kw;
 	const int offL = P.koff, offR = kw - P.koff - 1;
 	const bool interior = pos >= offL && pos < extent - offR;
@@ -131,20 +134,20 @@ __device__ __forceinline__ bool convOne(const ConvParams& P, const float* s, int
 			float v[KW > 0 ? KW : 1];
 #pragma unroll
 			for (int i = 0; i < KW; i++) v[i] = s[i * step];
-			total = v[0] * P.k[0];
+			total = v[0] * kc[0];
 #pragma unroll
-			for (int i = 1; i < KW; i++) total += v[i] * P.k[i];
+			for (int i = 1; i < KW; i++) total += v[i] * kc[i];
 		} else {
-			total = P.unrolled ? s[0] * P.k[0] : 0.0f + s[0] * P.k[0];
+			total = P.unrolled ? s[0] * kc[0] : 0.0f + s[0] * kc[0];
 			int i = 1;
 			for (; i + 4 <= kw; i += 4) {
 				const float v0 = s[i * step], v1 = s[(i + 1) * step], v2 = s[(i + 2) * step], v3 = s[(i + 3) * step];
-				total += v0 * P.k[i];
-				total += v1 * P.k[i + 1];
-				total += v2 * P.k[i + 2];
-				total += v3 * P.k[i + 3];
+				total += v0 * kc[i];
+				total += v1 * kc[i + 1];
+				total += v2 * kc[i + 2];
+				total += v3 * kc[i + 3];
 			}
-			for (; i < kw; i++) total += s[i * step] * P.k[i];
+			for (; i < kw; i++) total += s[i * step] * kc[i];
 		}
 		result = total;
 		return true;
@@ -154,7 +157,7 @@ __device__ __forceinline__ bool convOne(const ConvParams& P, const float* s, int
 	const int k1 = min(kw, extent - pos + offL);
 	float total = 0, weight = 0;
 	for (int k = k0; k < k1; k++) {
-		const float w = P.k[k];
+		const float w = kc[k];
 		weight += w;
 		total += s[k * step] * w;
 	}
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void k_conv_h_tile(ConvParams P, int padL, int
 				if (x >= P.koff && x < P.width - offRh) dst[x] = t[j];
 				else {
 					float r;
-					if (convOne<KW>(P, row + xl, 1, x, P.width, r)) dst[x] = r;
+					if (convOne<KW>(P, row + xl, 1, x, P.width, r, kl)) dst[x] = r;
 				}
 			}
 			continue;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256) void k_conv_h_tile(ConvParams P, int padL, int
 		for (int j = 0; j < 4; j++) {
 			const int xl = lane + 64 * j, x = xt0 + xl;
 			float r;
-			if (x < P.width && convOne<KW>(P, row + xl, 1, x, P.width, r)) dst[x] = r;
+			if (x < P.width && convOne<KW>(P, row + xl, 1, x, P.width, r, kl)) dst[x] = r;
 		}
 	}
 }
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv_v_tile(ConvParams P) {
 		float r[4];
 		bool wr = true;
 #pragma unroll
-		for (int j = 0; j < 4; j++) wr = convOne<KW>(P, s + j, CT_W, y, P.height, r[j]);   // same position class for the four columns
+		for (int j = 0; j < 4; j++) wr = convOne<KW>(P, s + j, CT_W, y, P.height, r[j], kl);   // same position class for the four columns
 		if (!wr) continue;
 		float* dst = outImg + (long long)y * P.outStride + x;
 		if (x + 3 < P.width) *reinterpret_cast<float4*>(dst) = make_float4(r[0], r[1], r[2], r[3]);
