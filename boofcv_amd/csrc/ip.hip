@@ -554,14 +554,25 @@ __global__ __launch_bounds__(64 * WPB) void k_blur_fused(ConvParams P) {
 		float v[4 * NL];
 #pragma unroll
 		for (int c = 0; c < NL; c++) { v[4 * c] = buf[c].x; v[4 * c + 1] = buf[c].y; v[4 * c + 2] = buf[c].z; v[4 * c + 3] = buf[c].w; }
+		if (colsInterior) {
+			// the four columns as two packed pairs: column j's tap i is v[PL - R + j + i], so the pairs are neighbouring array elements;
+			// component-wise the reference's expression (total = s0*k0; total += s_i*k_i), half the additions of four scalar chains
+			typedef float f32x2 __attribute__((ext_vector_type(2)));
+			f32x2 lo = f32x2{v[PL - R], v[PL - R + 1]} * P.k[0], hi = f32x2{v[PL - R + 2], v[PL - R + 3]} * P.k[0];
+#pragma unroll
+			for (int i = 1; i < KW; i++) {
+				lo += f32x2{v[PL - R + i], v[PL - R + 1 + i]} * P.k[i];
+				hi += f32x2{v[PL - R + 2 + i], v[PL - R + 3 + i]} * P.k[i];
+			}
+			return make_float4(lo.x, lo.y, hi.x, hi.y);
+		}
 		float r[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			float t[KW];
 #pragma unroll
 			for (int i = 0; i < KW; i++) t[i] = v[PL - R + j + i];
-			if (colsInterior) r[j] = blurTapsInterior<KW>(t, P.k);
-			else r[j] = (x + j >= R && x + j < W - R) ? blurTapsInterior<KW>(t, P.k) : blurTapsBorder<KW>(t, P.k, x + j - R, W);
+			r[j] = (x + j >= R && x + j < W - R) ? blurTapsInterior<KW>(t, P.k) : blurTapsBorder<KW>(t, P.k, x + j - R, W);
 		}
 		return make_float4(r[0], r[1], r[2], r[3]);
 	};
