@@ -130,8 +130,10 @@ class _PinnedPool:
     descriptors, match lists -- so that their copies are DMA transfers instead of staged pageable copies (what a JNI provider gets from direct
     ByteBuffers over the same allocator).  Blocks are recycled by size class when the numpy arrays built on them are garbage collected."""
     _free = {}      # size class -> [address]
+    _pooled = 0     # bytes sitting in _free
     _closed = False
     MIN = 4096
+    MAX_POOLED = 1 << 30   # blocks released beyond this go back to the runtime instead of the pool
 
     @classmethod
     def _size_class(cls, nbytes):
@@ -151,6 +153,7 @@ class _PinnedPool:
         if lst:
             try:
                 addr = lst.pop()      # (list.pop is atomic; another thread may have taken the last block in between)
+                cls._pooled -= size
             except IndexError:
                 addr = None
         if addr is None:
@@ -166,7 +169,11 @@ class _PinnedPool:
     def _release(cls, addr, size, _finalizing=sys.is_finalizing):
         if cls._closed or _finalizing():
             return   # the exit hook has run (or the interpreter is going down): the runtime reclaims the block
+        if cls._pooled + size > cls.MAX_POOLED:
+            _lib.load().bhip_host_free(C.c_void_p(addr))
+            return
         cls._free.setdefault(size, []).append(addr)
+        cls._pooled += size
 
     @classmethod
     def arrays(cls, ctx, specs):
@@ -191,6 +198,7 @@ class _PinnedPool:
             for addr in lst:
                 L.bhip_host_free(C.c_void_p(addr))
         cls._free.clear()
+        cls._pooled = 0
 
 
 atexit.register(_PinnedPool._close)   # registered after Context._close_all, so it runs before it (contexts are still alive)
