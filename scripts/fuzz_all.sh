@@ -1,7 +1,8 @@
 # the wide parity sweeps whose totals DESIGN.md quotes; writes gpurun_out/fuzz_summary.txt (copied to profiles/rNN_fuzz_summary.txt)
 out=gpurun_out/fuzz_summary.txt
-echo "wide parity sweeps, GPU (libboofhip.so through the C ABI) against the CPU oracle; $(date -u +%Y-%m-%dT%H:%MZ); commit $(cat gpurun_out/.commit 2>/dev/null)" > $out
-for job in "fuzz_parity 301 ${FUZZ_PARITY_CASES:-1200}" "fuzz_parity 302 ${FUZZ_PARITY_CASES:-1200}" "fuzz_assoc 301 ${FUZZ_ASSOC_CASES:-3000}" "fuzz_assoc 302 ${FUZZ_ASSOC_CASES:-3000}" "fuzz_ip 301 ${FUZZ_IP_CASES:-1500}" "fuzz_ip 302 ${FUZZ_IP_CASES:-1500}"; do
+echo "wide parity sweeps, GPU (libboofhip.so through the C ABI) against the CPU oracle; $(date -u +%Y-%m-%dT%H:%MZ); commit ${FUZZ_COMMIT:-unknown}" > $out
+S1=${FUZZ_SEED1:-301}; S2=${FUZZ_SEED2:-302}
+for job in "fuzz_parity $S1 ${FUZZ_PARITY_CASES:-1200}" "fuzz_parity $S2 ${FUZZ_PARITY_CASES:-1200}" "fuzz_assoc $S1 ${FUZZ_ASSOC_CASES:-3000}" "fuzz_assoc $S2 ${FUZZ_ASSOC_CASES:-3000}" "fuzz_ip $S1 ${FUZZ_IP_CASES:-1500}" "fuzz_ip $S2 ${FUZZ_IP_CASES:-1500}"; do
   set -- $job
   echo "== python scripts/$1.py $2 $3" >> $out
   timeout -k 10 1000 python scripts/$1.py $2 $3 > gpurun_out/$1_$2.log 2>&1

@@ -23,5 +23,6 @@ struct JNINativeInterface_ {
 	void (*SetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, const jlong*);
 	void* (*GetDirectBufferAddress)(JNIEnv*, jobject);
 	jstring (*NewStringUTF)(JNIEnv*, const char*);
+	jobject (*NewDirectByteBuffer)(JNIEnv*, void*, jlong);
 };
 #endif

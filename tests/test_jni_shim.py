@@ -24,10 +24,16 @@ def test_generated_files_are_current_and_complete():
 
 
 def test_shim_is_valid_c_against_the_jni_signatures():
-    cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-parameter", "-I", os.path.join(ROOT, "tests", "jni_syntax"), "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "integration", "jni", "boofhip_jni.c")]
-    p = subprocess.run(cmd, capture_output=True, text=True)
-    assert p.returncode == 0, p.stderr
+    for src in ("boofhip_jni.c", "boofhip_jni_buffers.c"):   # the generated shim and its hand-written companion (page-locked direct buffers)
+        cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-parameter", "-I", os.path.join(ROOT, "tests", "jni_syntax"), "-I", os.path.join(ROOT, "include"),
+               os.path.join(ROOT, "integration", "jni", src)]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+    # every native of the companion's Java class has its C function
+    j = open(os.path.join(ROOT, "integration", "java", "boofcv", "hip", "PinnedBuffersHip.java")).read()
+    c = open(os.path.join(ROOT, "integration", "jni", "boofhip_jni_buffers.c")).read()
+    natives = set(re.findall(r"native \S+ (\w+)\(", j))
+    assert natives == set(re.findall(r"^BHIP_JNI\(\w+, (\w+)\)", c, flags=re.M)), natives   # (line starts: not the macro's own definition)
 
 
 def test_provider_sources_call_existing_natives():
